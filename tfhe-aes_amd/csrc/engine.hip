@@ -1,0 +1,548 @@
+// Engine behind the C ABI in include/tfhe_aes_hip.h: context, key upload, ciphertext pool and
+// the per-stage batch submitter.  One context per GPU, one submitting thread per context.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/tfhe_aes_hip.h"
+#include "ks_kernel.h"
+#include "pbs_kernel.h"
+
+using namespace tfa;
+
+namespace {
+constexpr uint32_t kPoolStridePad = 4;   // pool rows padded to a multiple of 4 words (16 B)
+constexpr int kStagingRing = 4;
+
+struct EventPair {
+    hipEvent_t a, b;
+    int kind;  // 0 = pbs, 1 = ks
+};
+}  // namespace
+
+struct tfa_ctx {
+    tfa_params p;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    // keys
+    c64 *d_bsk_f = nullptr;
+    uint32_t *d_ksk = nullptr;
+    c64 *d_tw = nullptr;
+    uint32_t ksk_stride = 0;
+    bool have_keys = false;
+    // pool
+    uint32_t *d_pool = nullptr;
+    uint32_t pool_slots = 0, pool_stride = 0;
+    // per-stage scratch (grow-only)
+    uint32_t *d_big = nullptr;
+    uint32_t big_cap = 0, big_stride = 0;
+    unsigned char *d_jobs = nullptr;
+    size_t jobs_cap = 0;
+    unsigned char *h_stage[kStagingRing] = {nullptr, nullptr, nullptr, nullptr};
+    size_t h_stage_cap[kStagingRing] = {0, 0, 0, 0};
+    hipEvent_t h_stage_ev[kStagingRing] = {nullptr, nullptr, nullptr, nullptr};
+    int ring = 0;
+    uint32_t *d_io = nullptr;  // staging for pool read/write and the host-buffer entry points
+    size_t io_cap = 0;
+    // stats
+    tfa_stats stats{};
+    bool profiling = false;
+    std::vector<EventPair> pending;
+};
+
+#define HIPCHK(ctx, call)                                                                                      \
+    do {                                                                                                       \
+        hipError_t e_ = (call);                                                                                \
+        if (e_ != hipSuccess) {                                                                                \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                                    \
+            return TFA_EHIP;                                                                                   \
+        }                                                                                                      \
+    } while (0)
+
+static int fail(tfa_ctx *ctx, int code, const std::string &msg) {
+    ctx->err = msg;
+    return code;
+}
+
+static int ensure_io(tfa_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->io_cap) return TFA_OK;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_io) HIPCHK(ctx, hipFree(ctx->d_io));
+    ctx->d_io = nullptr;
+    ctx->io_cap = 0;
+    size_t cap = bytes + bytes / 4;
+    HIPCHK(ctx, hipMalloc(&ctx->d_io, cap));
+    ctx->io_cap = cap;
+    return TFA_OK;
+}
+static int ensure_big(tfa_ctx *ctx, uint32_t rows) {
+    if (rows <= ctx->big_cap) return TFA_OK;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_big) HIPCHK(ctx, hipFree(ctx->d_big));
+    ctx->d_big = nullptr;
+    ctx->big_cap = 0;
+    uint32_t cap = rows + rows / 4 + 64;
+    HIPCHK(ctx, hipMalloc(&ctx->d_big, (size_t)cap * ctx->big_stride * sizeof(uint32_t)));
+    ctx->big_cap = cap;
+    return TFA_OK;
+}
+static int ensure_jobs(tfa_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->jobs_cap) return TFA_OK;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->d_jobs) HIPCHK(ctx, hipFree(ctx->d_jobs));
+    ctx->d_jobs = nullptr;
+    ctx->jobs_cap = 0;
+    size_t cap = bytes + bytes / 4 + 4096;
+    HIPCHK(ctx, hipMalloc(&ctx->d_jobs, cap));
+    ctx->jobs_cap = cap;
+    return TFA_OK;
+}
+// pinned staging ring slot, safe to overwrite once its previous upload has executed
+static int staging(tfa_ctx *ctx, size_t bytes, unsigned char **out) {
+    int s = ctx->ring;
+    ctx->ring = (ctx->ring + 1) % kStagingRing;
+    if (ctx->h_stage_ev[s]) HIPCHK(ctx, hipEventSynchronize(ctx->h_stage_ev[s]));
+    if (bytes > ctx->h_stage_cap[s]) {
+        if (ctx->h_stage[s]) HIPCHK(ctx, hipHostFree(ctx->h_stage[s]));
+        ctx->h_stage[s] = nullptr;
+        ctx->h_stage_cap[s] = 0;
+        size_t cap = bytes + bytes / 4 + 4096;
+        HIPCHK(ctx, hipHostMalloc(&ctx->h_stage[s], cap, hipHostMallocDefault));
+        ctx->h_stage_cap[s] = cap;
+    }
+    if (!ctx->h_stage_ev[s]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->h_stage_ev[s], hipEventDisableTiming));
+    *out = ctx->h_stage[s];
+    return s;
+}
+
+static int drain_events(tfa_ctx *ctx) {
+    for (auto &ep : ctx->pending) {
+        float ms = 0.f;
+        HIPCHK(ctx, hipEventSynchronize(ep.b));
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ep.a, ep.b));
+        if (ep.kind == 0) {
+            ctx->stats.pbs_kernel_ms += ms;
+            ctx->stats.pbs_launches++;
+        } else {
+            ctx->stats.ks_kernel_ms += ms;
+            ctx->stats.ks_launches++;
+        }
+        hipEventDestroy(ep.a);
+        hipEventDestroy(ep.b);
+    }
+    ctx->pending.clear();
+    return TFA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" void tfa_default_params(tfa_params *p) {
+    p->lwe_dimension = 805;
+    p->glwe_dimension = 3;
+    p->polynomial_size = 512;
+    p->pbs_base_log = 10;
+    p->pbs_level = 2;
+    p->ks_base_log = 3;
+    p->ks_level = 5;
+    p->lwe_noise_std = 5.8615896642671336e-06;
+    p->glwe_noise_std = 9.315272083503367e-10;
+}
+extern "C" uint64_t tfa_bsk_words(const tfa_params *p) {
+    uint64_t k1 = p->glwe_dimension + 1;
+    return (uint64_t)p->lwe_dimension * p->pbs_level * k1 * k1 * p->polynomial_size;
+}
+extern "C" uint64_t tfa_ksk_words(const tfa_params *p) {
+    return (uint64_t)p->glwe_dimension * p->polynomial_size * p->ks_level * (p->lwe_dimension + 1);
+}
+
+extern "C" int tfa_ctx_create(const tfa_params *p, int hip_device, tfa_ctx **out) {
+    if (!p || !out) return TFA_EINVAL;
+    *out = nullptr;
+    if (p->glwe_dimension != 3 || p->polynomial_size != 512 || p->pbs_base_log != 10 || p->pbs_level != 2) return TFA_EINVAL;
+    if (p->lwe_dimension < 1 || p->lwe_dimension > 830 || p->ks_level < 1 || p->ks_level > kKsMaxLevels ||
+        p->ks_base_log * p->ks_level > 31 || p->ks_base_log < 1)
+        return TFA_EINVAL;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || hip_device < 0 || hip_device >= n_dev) return TFA_EHIP;
+    tfa_ctx *ctx = new (std::nothrow) tfa_ctx();
+    if (!ctx) return TFA_ENOMEM;
+    ctx->p = *p;
+    ctx->device = hip_device;
+    ctx->pool_stride = (p->lwe_dimension + 1 + kPoolStridePad - 1) / kPoolStridePad * kPoolStridePad;
+    ctx->ksk_stride = ctx->pool_stride;
+    ctx->big_stride = (p->glwe_dimension * p->polynomial_size + 1 + 3) / 4 * 4;
+    *out = ctx;  // handed out even on failure below so the caller can read the message and destroy it
+    HIPCHK(ctx, hipSetDevice(hip_device));
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    // per-lane twiddles e^{i pi t (1 + 4 r)/512}, [r][t]
+    std::vector<c64> tw(256);
+    for (int r = 0; r < 16; r++)
+        for (int t = 0; t < 16; t++) {
+            long double a = 3.14159265358979323846264338327950288L * (long double)(t * (1 + 4 * r)) / 512.0L;
+            tw[r * 16 + t] = c64{(double)cosl(a), (double)sinl(a)};
+        }
+    HIPCHK(ctx, hipMalloc(&ctx->d_tw, sizeof(c64) * 256));
+    HIPCHK(ctx, hipMemcpy(ctx->d_tw, tw.data(), sizeof(c64) * 256, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kPbsLdsBytes));
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bsk_convert_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kPbsLdsBytes));
+    return TFA_OK;
+}
+
+extern "C" int tfa_ctx_destroy(tfa_ctx *ctx) {
+    if (!ctx) return TFA_EINVAL;
+    hipSetDevice(ctx->device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    for (auto &ep : ctx->pending) {
+        hipEventDestroy(ep.a);
+        hipEventDestroy(ep.b);
+    }
+    hipFree(ctx->d_bsk_f);
+    hipFree(ctx->d_ksk);
+    hipFree(ctx->d_tw);
+    hipFree(ctx->d_pool);
+    hipFree(ctx->d_big);
+    hipFree(ctx->d_jobs);
+    hipFree(ctx->d_io);
+    for (int s = 0; s < kStagingRing; s++) {
+        if (ctx->h_stage[s]) hipHostFree(ctx->h_stage[s]);
+        if (ctx->h_stage_ev[s]) hipEventDestroy(ctx->h_stage_ev[s]);
+    }
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return TFA_OK;
+}
+
+extern "C" const char *tfa_last_error(tfa_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int tfa_keys_upload(tfa_ctx *ctx, const uint32_t *bsk, const uint32_t *ksk) {
+    if (!ctx || !bsk || !ksk) return TFA_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const tfa_params &p = ctx->p;
+    const uint64_t bsk_words = tfa_bsk_words(&p);
+    const uint32_t n = p.lwe_dimension, kN_ = p.glwe_dimension * p.polynomial_size;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (!ctx->d_bsk_f) HIPCHK(ctx, hipMalloc(&ctx->d_bsk_f, bsk_words / 2 * sizeof(c64)));  // N/2 complex per polynomial
+    if (!ctx->d_ksk) HIPCHK(ctx, hipMalloc(&ctx->d_ksk, (size_t)kN_ * p.ks_level * ctx->ksk_stride * sizeof(uint32_t)));
+    // KSK rows padded to the pool stride
+    HIPCHK(ctx, hipMemset(ctx->d_ksk, 0, (size_t)kN_ * p.ks_level * ctx->ksk_stride * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMemcpy2D(ctx->d_ksk, ctx->ksk_stride * sizeof(uint32_t), ksk, (n + 1) * sizeof(uint32_t), (n + 1) * sizeof(uint32_t),
+                            (size_t)kN_ * p.ks_level, hipMemcpyHostToDevice));
+    // BSK: upload the standard domain, transform on the device
+    uint32_t *d_std = nullptr;
+    HIPCHK(ctx, hipMalloc(&d_std, bsk_words * sizeof(uint32_t)));
+    hipError_t e = hipMemcpy(d_std, bsk, bsk_words * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        const uint32_t rows = n * p.pbs_level * (p.glwe_dimension + 1);
+        hipLaunchKernelGGL(bsk_convert_kernel, dim3((rows + kWavesPerBlock - 1) / kWavesPerBlock), dim3(256), kPbsLdsBytes, ctx->stream, d_std,
+                           ctx->d_bsk_f, ctx->d_tw, rows);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+    hipFree(d_std);
+    if (e != hipSuccess) return fail(ctx, TFA_EHIP, std::string("bsk upload/convert: ") + hipGetErrorString(e));
+    ctx->have_keys = true;
+    return TFA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int tfa_pool_reserve(tfa_ctx *ctx, uint32_t n_slots) {
+    if (!ctx || n_slots == 0) return TFA_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (n_slots <= ctx->pool_slots) return TFA_OK;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    uint32_t *np_ = nullptr;
+    size_t bytes = (size_t)n_slots * ctx->pool_stride * sizeof(uint32_t);
+    if (hipMalloc(&np_, bytes) != hipSuccess) return fail(ctx, TFA_ENOMEM, "pool allocation failed");
+    hipError_t e = hipMemset(np_, 0, bytes);
+    if (e == hipSuccess && ctx->d_pool)
+        e = hipMemcpy(np_, ctx->d_pool, (size_t)ctx->pool_slots * ctx->pool_stride * sizeof(uint32_t), hipMemcpyDeviceToDevice);
+    if (e != hipSuccess) {
+        hipFree(np_);
+        return fail(ctx, TFA_EHIP, std::string("pool grow: ") + hipGetErrorString(e));
+    }
+    if (ctx->d_pool) hipFree(ctx->d_pool);
+    ctx->d_pool = np_;
+    ctx->pool_slots = n_slots;
+    return TFA_OK;
+}
+
+static int check_slots(tfa_ctx *ctx, const uint32_t *slots, uint32_t count) {
+    for (uint32_t i = 0; i < count; i++)
+        if (slots[i] >= ctx->pool_slots) return fail(ctx, TFA_EINVAL, "slot index out of range");
+    return TFA_OK;
+}
+
+extern "C" int tfa_pool_write(tfa_ctx *ctx, const uint32_t *slots, uint32_t count, const uint32_t *lwe) {
+    if (!ctx || !slots || !lwe) return TFA_EINVAL;
+    if (count == 0) return TFA_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = check_slots(ctx, slots, count);
+    if (rc) return rc;
+    const uint32_t words = ctx->p.lwe_dimension + 1;
+    size_t data_bytes = (size_t)count * words * sizeof(uint32_t), slot_bytes = (size_t)count * sizeof(uint32_t);
+    size_t slot_off = (data_bytes + 15) / 16 * 16;
+    rc = ensure_io(ctx, slot_off + slot_bytes);
+    if (rc) return rc;
+    unsigned char *base = reinterpret_cast<unsigned char *>(ctx->d_io);
+    HIPCHK(ctx, hipMemcpyAsync(base, lwe, data_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(base + slot_off, slots, slot_bytes, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(pool_scatter_kernel, dim3(count), dim3(256), 0, ctx->stream, ctx->d_pool, ctx->pool_stride,
+                       reinterpret_cast<const uint32_t *>(base + slot_off), reinterpret_cast<const uint32_t *>(base), words);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host buffers may be reused on return
+    return TFA_OK;
+}
+
+extern "C" int tfa_pool_read(tfa_ctx *ctx, const uint32_t *slots, uint32_t count, uint32_t *lwe) {
+    if (!ctx || !slots || !lwe) return TFA_EINVAL;
+    if (count == 0) return TFA_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = check_slots(ctx, slots, count);
+    if (rc) return rc;
+    const uint32_t words = ctx->p.lwe_dimension + 1;
+    size_t data_bytes = (size_t)count * words * sizeof(uint32_t), slot_bytes = (size_t)count * sizeof(uint32_t);
+    size_t slot_off = (data_bytes + 15) / 16 * 16;
+    rc = ensure_io(ctx, slot_off + slot_bytes);
+    if (rc) return rc;
+    unsigned char *base = reinterpret_cast<unsigned char *>(ctx->d_io);
+    HIPCHK(ctx, hipMemcpyAsync(base + slot_off, slots, slot_bytes, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(pool_gather_kernel, dim3(count), dim3(256), 0, ctx->stream, ctx->d_pool, ctx->pool_stride,
+                       reinterpret_cast<const uint32_t *>(base + slot_off), reinterpret_cast<uint32_t *>(base), words);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(lwe, base, data_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return TFA_OK;
+}
+
+extern "C" int tfa_pool_device_ptr(tfa_ctx *ctx, void **dptr, uint32_t *stride_words, uint32_t *n_slots) {
+    if (!ctx) return TFA_EINVAL;
+    if (dptr) *dptr = ctx->d_pool;
+    if (stride_words) *stride_words = ctx->pool_stride;
+    if (n_slots) *n_slots = ctx->pool_slots;
+    return TFA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+static int launch_pbs(tfa_ctx *ctx, const uint32_t *in_base, uint32_t in_stride, const PbsJob *d_jobs, uint32_t n_jobs, uint32_t steps,
+                      uint32_t *acc_out) {
+    if (n_jobs == 0) return TFA_OK;
+    EventPair ep{nullptr, nullptr, 0};
+    if (ctx->profiling) {
+        HIPCHK(ctx, hipEventCreate(&ep.a));
+        HIPCHK(ctx, hipEventCreate(&ep.b));
+        HIPCHK(ctx, hipEventRecord(ep.a, ctx->stream));
+    }
+    hipLaunchKernelGGL(pbs_kernel, dim3((n_jobs + kWavesPerBlock - 1) / kWavesPerBlock), dim3(256), kPbsLdsBytes, ctx->stream, in_base, in_stride,
+                       d_jobs, n_jobs, ctx->d_bsk_f, ctx->d_tw, ctx->p.lwe_dimension, steps, ctx->d_big, ctx->big_stride, acc_out);
+    HIPCHK(ctx, hipGetLastError());
+    if (ctx->profiling) {
+        HIPCHK(ctx, hipEventRecord(ep.b, ctx->stream));
+        ctx->pending.push_back(ep);
+    }
+    ctx->stats.pbs_count += n_jobs;
+    return TFA_OK;
+}
+
+static int launch_ks(tfa_ctx *ctx, const KsJob *d_jobs, uint32_t n_jobs, uint32_t *out_base, uint32_t out_stride) {
+    if (n_jobs == 0) return TFA_OK;
+    const tfa_params &p = ctx->p;
+    EventPair ep{nullptr, nullptr, 1};
+    if (ctx->profiling) {
+        HIPCHK(ctx, hipEventCreate(&ep.a));
+        HIPCHK(ctx, hipEventCreate(&ep.b));
+        HIPCHK(ctx, hipEventRecord(ep.a, ctx->stream));
+    }
+    const uint32_t big_dim = p.glwe_dimension * p.polynomial_size;
+#define KS_LAUNCH(TG)                                                                                                                         \
+    hipLaunchKernelGGL(keyswitch_kernel<TG>, dim3((n_jobs + TG - 1) / TG), dim3(832), kKsChunk *p.ks_level *TG * sizeof(int32_t), ctx->stream, \
+                       ctx->d_big, ctx->big_stride, d_jobs, n_jobs, ctx->d_ksk, ctx->ksk_stride, p.lwe_dimension, big_dim, p.ks_base_log,     \
+                       p.ks_level, out_base, out_stride)
+    if (n_jobs >= 32 * 256)
+        KS_LAUNCH(32);
+    else if (n_jobs >= 8 * 128)
+        KS_LAUNCH(8);
+    else
+        KS_LAUNCH(2);
+#undef KS_LAUNCH
+    HIPCHK(ctx, hipGetLastError());
+    if (ctx->profiling) {
+        HIPCHK(ctx, hipEventRecord(ep.b, ctx->stream));
+        ctx->pending.push_back(ep);
+    }
+    ctx->stats.ks_count += n_jobs;
+    return TFA_OK;
+}
+
+extern "C" int tfa_stage_submit(tfa_ctx *ctx, const tfa_gate *gates, uint32_t count) {
+    if (!ctx || (!gates && count)) return TFA_EINVAL;
+    if (count == 0) return TFA_OK;
+    if (!ctx->have_keys) return fail(ctx, TFA_ESTATE, "tfa_stage_submit before tfa_keys_upload");
+    if (!ctx->d_pool) return fail(ctx, TFA_ESTATE, "tfa_stage_submit before tfa_pool_reserve");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // translate gates into bootstrap, keyswitch and linear jobs
+    uint32_t n_pbs = 0, n_ks = 0, n_lin = 0;
+    for (uint32_t i = 0; i < count; i++) {
+        const tfa_gate &g = gates[i];
+        if (g.op > TFA_COPY) return fail(ctx, TFA_EINVAL, "unknown gate opcode");
+        if (g.in0 >= ctx->pool_slots || g.out >= ctx->pool_slots) return fail(ctx, TFA_EINVAL, "gate slot out of range");
+        if (g.op <= TFA_MUX && g.in1 >= ctx->pool_slots) return fail(ctx, TFA_EINVAL, "gate slot out of range");
+        if (g.op == TFA_MUX && g.in2 >= ctx->pool_slots) return fail(ctx, TFA_EINVAL, "gate slot out of range");
+        if (g.op == TFA_MUX) {
+            n_pbs += 2;
+            n_ks++;
+        } else if (g.op <= TFA_XNOR) {
+            n_pbs++;
+            n_ks++;
+        } else
+            n_lin++;
+    }
+    const size_t off_ks = (sizeof(PbsJob) * n_pbs + 15) / 16 * 16, off_lin = off_ks + (sizeof(KsJob) * n_ks + 15) / 16 * 16;
+    const size_t total = off_lin + sizeof(LinJob) * n_lin;
+    unsigned char *h = nullptr;
+    int slot = staging(ctx, total, &h);
+    if (slot < 0) return slot;
+    PbsJob *pj = reinterpret_cast<PbsJob *>(h);
+    KsJob *kj = reinterpret_cast<KsJob *>(h + off_ks);
+    LinJob *lj = reinterpret_cast<LinJob *>(h + off_lin);
+    const uint32_t T = 1u << 29;
+    uint32_t ip = 0, ik = 0, il = 0;
+    for (uint32_t i = 0; i < count; i++) {
+        const tfa_gate &g = gates[i];
+        const int32_t s0 = (g.neg & 1) ? -1 : 1, s1 = (g.neg & 2) ? -1 : 1, s2 = (g.neg & 4) ? -1 : 1;
+        PbsJob j{};
+        switch (g.op) {
+        case TFA_AND: j = PbsJob{g.in0, g.in1, s0, s1, 0u - T, {0, 0, 0}}; break;
+        case TFA_NAND: j = PbsJob{g.in0, g.in1, -s0, -s1, T, {0, 0, 0}}; break;
+        case TFA_OR: j = PbsJob{g.in0, g.in1, s0, s1, T, {0, 0, 0}}; break;
+        case TFA_NOR: j = PbsJob{g.in0, g.in1, -s0, -s1, 0u - T, {0, 0, 0}}; break;
+        case TFA_XOR: j = PbsJob{g.in0, g.in1, 2 * s0, 2 * s1, 2u * T, {0, 0, 0}}; break;
+        case TFA_XNOR: j = PbsJob{g.in0, g.in1, -2 * s0, -2 * s1, 0u - 2u * T, {0, 0, 0}}; break;
+        case TFA_MUX:
+            pj[ip] = PbsJob{g.in0, g.in1, s0, s1, 0u - T, {0, 0, 0}};    // cond AND then
+            pj[ip + 1] = PbsJob{g.in0, g.in2, -s0, s2, 0u - T, {0, 0, 0}};  // (NOT cond) AND else
+            kj[ik++] = KsJob{ip, ip + 1, T, g.out};
+            ip += 2;
+            continue;
+        case TFA_NOT: lj[il++] = LinJob{g.in0, g.out, -s0, 0}; continue;
+        default: lj[il++] = LinJob{g.in0, g.out, s0, 0}; continue;
+        }
+        pj[ip] = j;
+        kj[ik++] = KsJob{ip, kNoSlot, 0u, g.out};
+        ip++;
+    }
+    int rc = ensure_jobs(ctx, total);
+    if (rc) return rc;
+    rc = ensure_big(ctx, n_pbs);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_jobs, h, total, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->h_stage_ev[slot], ctx->stream));
+    rc = launch_pbs(ctx, ctx->d_pool, ctx->pool_stride, reinterpret_cast<const PbsJob *>(ctx->d_jobs), n_pbs, ctx->p.lwe_dimension, nullptr);
+    if (rc) return rc;
+    rc = launch_ks(ctx, reinterpret_cast<const KsJob *>(ctx->d_jobs + off_ks), n_ks, ctx->d_pool, ctx->pool_stride);
+    if (rc) return rc;
+    if (n_lin) {
+        hipLaunchKernelGGL(lin_kernel, dim3(n_lin), dim3(256), 0, ctx->stream, ctx->d_pool, ctx->pool_stride,
+                           reinterpret_cast<const LinJob *>(ctx->d_jobs + off_lin), n_lin, ctx->p.lwe_dimension);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    ctx->stats.gate_count += count;
+    ctx->stats.stage_count++;
+    return TFA_OK;
+}
+
+extern "C" int tfa_sync(tfa_ctx *ctx) {
+    if (!ctx) return TFA_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return drain_events(ctx);
+}
+
+// ---------------------------------------------------------------------------------------------
+static int bootstrap_common(tfa_ctx *ctx, const uint32_t *lwe_in, uint32_t count, uint32_t steps, uint32_t *acc_host, uint32_t *big_host) {
+    if (!ctx || !lwe_in || count == 0) return TFA_EINVAL;
+    if (!ctx->have_keys) return fail(ctx, TFA_ESTATE, "bootstrap before tfa_keys_upload");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const tfa_params &p = ctx->p;
+    const uint32_t words = p.lwe_dimension + 1, kN_ = p.glwe_dimension * p.polynomial_size;
+    const size_t in_bytes = (size_t)count * words * sizeof(uint32_t);
+    const size_t acc_off = (in_bytes + 255) / 256 * 256;
+    const size_t acc_bytes = acc_host ? (size_t)count * (kN_ + p.polynomial_size) * sizeof(uint32_t) : 0;
+    int rc = ensure_io(ctx, acc_off + acc_bytes);
+    if (rc) return rc;
+    rc = ensure_big(ctx, count);
+    if (rc) return rc;
+    std::vector<PbsJob> jobs(count);
+    for (uint32_t i = 0; i < count; i++) jobs[i] = PbsJob{i, i, 1, 0, 0u, {0, 0, 0}};
+    rc = ensure_jobs(ctx, sizeof(PbsJob) * count);
+    if (rc) return rc;
+    unsigned char *io = reinterpret_cast<unsigned char *>(ctx->d_io);
+    HIPCHK(ctx, hipMemcpyAsync(io, lwe_in, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_jobs, jobs.data(), sizeof(PbsJob) * count, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    rc = launch_pbs(ctx, reinterpret_cast<const uint32_t *>(io), words, reinterpret_cast<const PbsJob *>(ctx->d_jobs), count, steps,
+                    acc_host ? reinterpret_cast<uint32_t *>(io + acc_off) : nullptr);
+    if (rc) return rc;
+    if (acc_host)
+        HIPCHK(ctx, hipMemcpyAsync(acc_host, io + acc_off, acc_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    else
+        HIPCHK(ctx, hipMemcpy2DAsync(big_host, (kN_ + 1) * sizeof(uint32_t), ctx->d_big, ctx->big_stride * sizeof(uint32_t),
+                                     (kN_ + 1) * sizeof(uint32_t), count, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return drain_events(ctx);
+}
+
+extern "C" int tfa_bootstrap_batch(tfa_ctx *ctx, const uint32_t *lwe_in, uint32_t count, uint32_t *big_out) {
+    if (!big_out) return TFA_EINVAL;
+    return bootstrap_common(ctx, lwe_in, count, ctx ? ctx->p.lwe_dimension : 0, nullptr, big_out);
+}
+extern "C" int tfa_blind_rotate_batch(tfa_ctx *ctx, const uint32_t *lwe_in, uint32_t count, uint32_t steps, uint32_t *acc_out) {
+    if (!acc_out) return TFA_EINVAL;
+    return bootstrap_common(ctx, lwe_in, count, steps, acc_out, nullptr);
+}
+
+extern "C" int tfa_keyswitch_batch(tfa_ctx *ctx, const uint32_t *big_in, uint32_t count, uint32_t *lwe_out) {
+    if (!ctx || !big_in || !lwe_out || count == 0) return TFA_EINVAL;
+    if (!ctx->have_keys) return fail(ctx, TFA_ESTATE, "keyswitch before tfa_keys_upload");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const tfa_params &p = ctx->p;
+    const uint32_t words = p.lwe_dimension + 1, kN_ = p.glwe_dimension * p.polynomial_size;
+    int rc = ensure_big(ctx, count);
+    if (rc) return rc;
+    rc = ensure_io(ctx, (size_t)count * ctx->pool_stride * sizeof(uint32_t));
+    if (rc) return rc;
+    std::vector<KsJob> jobs(count);
+    for (uint32_t i = 0; i < count; i++) jobs[i] = KsJob{i, kNoSlot, 0u, i};
+    rc = ensure_jobs(ctx, sizeof(KsJob) * count);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_big, ctx->big_stride * sizeof(uint32_t), big_in, (kN_ + 1) * sizeof(uint32_t), (kN_ + 1) * sizeof(uint32_t),
+                                 count, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_jobs, jobs.data(), sizeof(KsJob) * count, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    rc = launch_ks(ctx, reinterpret_cast<const KsJob *>(ctx->d_jobs), count, ctx->d_io, ctx->pool_stride);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpy2DAsync(lwe_out, words * sizeof(uint32_t), ctx->d_io, ctx->pool_stride * sizeof(uint32_t), words * sizeof(uint32_t), count,
+                                 hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return drain_events(ctx);
+}
+
+extern "C" int tfa_set_profiling(tfa_ctx *ctx, int on) {
+    if (!ctx) return TFA_EINVAL;
+    ctx->profiling = on != 0;
+    return TFA_OK;
+}
+extern "C" int tfa_get_stats(tfa_ctx *ctx, tfa_stats *out) {
+    if (!ctx || !out) return TFA_EINVAL;
+    *out = ctx->stats;
+    return TFA_OK;
+}
+extern "C" int tfa_reset_stats(tfa_ctx *ctx) {
+    if (!ctx) return TFA_EINVAL;
+    int rc = tfa_sync(ctx);
+    ctx->stats = tfa_stats{};
+    return rc;
+}

@@ -1,0 +1,351 @@
+// Programmable bootstrap (gate linear combination + modulus switch + blind rotation + sample
+// extract) for gfx950, specialised for k = 3, N = 512, (beta, l) = (2^10, 2).
+//
+// Mapping: one 64-lane wavefront owns one bootstrap for all n blind-rotation steps.  The four
+// 16-lane rows of the wave (g = lane >> 4) each own one polynomial of the GLWE accumulator; lane
+// t = lane & 15 of a row holds the 32 coefficients j == t (mod 16) in registers.  A negacyclic
+// size-512 transform is a size-256 complex FFT computed as 16 x 16: a register-resident DFT16 per
+// lane, one 16 x 16 transpose through wave-private LDS, a second register DFT16.  The Fourier
+// domain multiply-accumulate with the bootstrapping key sums over the four rows with the gfx950
+// row/half swap instructions, so no workgroup barrier is needed anywhere in the loop.
+//
+// What the kernel computes follows tfhe-rs 0.11 (blind_rotate_assign / add_external_product_assign,
+// the engine under every ServerKey gate called at /root/reference/base/src/boolean_tree.rs:644-654).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tfa {
+
+constexpr int kN = 512;          // polynomial size
+constexpr int kK1 = 4;           // glwe_dimension + 1
+constexpr int kLevels = 2;       // pbs_level
+constexpr int kBaseLog = 10;     // pbs_base_log
+constexpr int kRotStride = 528;  // u32 words per polynomial in the rotation buffer (528 % 32 == 16)
+constexpr int kTrRow = 17;       // complex elements per padded transpose row
+constexpr int kTrGroup = 16 * kTrRow;
+constexpr int kWaveLdsBytes = 4 * kTrGroup * 16;  // 17408: transpose buffer, aliased by the rotation buffer
+constexpr int kABytes = 1664;                     // modulus-switched mask, u16[<=832]
+constexpr int kWavesPerBlock = 4;
+constexpr int kPbsLdsBytes = kWavesPerBlock * (kWaveLdsBytes + kABytes);
+
+// One bootstrap: u = ca*in[a] + cb*in[b] + (0,..,0,cst), all wrapping u32.
+struct PbsJob {
+    uint32_t a, b;
+    int32_t ca, cb;
+    uint32_t cst;
+    uint32_t pad[3];
+};
+
+struct c64 {
+    double x, y;
+};
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- register DFT16 --------------------------------------------------------------------------
+// S = +1: kernel e^{+2 pi i nk/16}; S = -1: its conjugate.
+template <int S>
+__device__ __forceinline__ void dft4(double &r0, double &i0, double &r1, double &i1, double &r2, double &i2, double &r3, double &i3) {
+    double t0r = r0 + r2, t0i = i0 + i2, t1r = r0 - r2, t1i = i0 - i2;
+    double t2r = r1 + r3, t2i = i1 + i3, dr = r1 - r3, di = i1 - i3;
+    double t3r = S > 0 ? -di : di, t3i = S > 0 ? dr : -dr;
+    r0 = t0r + t2r;
+    i0 = t0i + t2i;
+    r2 = t0r - t2r;
+    i2 = t0i - t2i;
+    r1 = t1r + t3r;
+    i1 = t1i + t3i;
+    r3 = t1r - t3r;
+    i3 = t1i - t3i;
+}
+template <int S>
+__device__ __forceinline__ void cmulc(double &r, double &i, double c, double s) {  // (r + i i) * (c + i S s)
+    double nr = r * c - (S > 0 ? i * s : -(i * s));
+    double ni = (S > 0 ? r * s : -(r * s)) + i * c;
+    r = nr;
+    i = ni;
+}
+template <int S>
+__device__ __forceinline__ void dft16(double (&re)[16], double (&im)[16]) {
+    constexpr double C1 = 0.9238795325112867, S1 = 0.3826834323650898, R = 0.7071067811865476;
+#pragma unroll
+    for (int n2 = 0; n2 < 4; n2++) dft4<S>(re[n2], im[n2], re[4 + n2], im[4 + n2], re[8 + n2], im[8 + n2], re[12 + n2], im[12 + n2]);
+    // position 4*k1 + n2 now holds u[n2][k1]; twiddle by W16^(n2*k1)
+    cmulc<S>(re[5], im[5], C1, S1);    // e = 1
+    cmulc<S>(re[6], im[6], R, R);      // e = 2
+    cmulc<S>(re[7], im[7], S1, C1);    // e = 3
+    cmulc<S>(re[9], im[9], R, R);      // e = 2
+    {                                  // e = 4: times S*i
+        double r = re[10], i = im[10];
+        re[10] = S > 0 ? -i : i;
+        im[10] = S > 0 ? r : -r;
+    }
+    cmulc<S>(re[11], im[11], -R, R);    // e = 6
+    cmulc<S>(re[13], im[13], S1, C1);   // e = 3
+    cmulc<S>(re[14], im[14], -R, R);    // e = 6
+    cmulc<S>(re[15], im[15], -C1, -S1); // e = 9
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++)
+        dft4<S>(re[4 * k1], im[4 * k1], re[4 * k1 + 1], im[4 * k1 + 1], re[4 * k1 + 2], im[4 * k1 + 2], re[4 * k1 + 3], im[4 * k1 + 3]);
+    // position 4*k1 + k2 holds X[k1 + 4*k2]: undo the digit reversal (register renaming only)
+    double tr[16], ti[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        tr[k] = re[4 * (k & 3) + (k >> 2)];
+        ti[k] = im[4 * (k & 3) + (k >> 2)];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        re[k] = tr[k];
+        im[k] = ti[k];
+    }
+}
+
+// e^{i pi n/32}, n = 0..15: the lane-independent part of the negacyclic twist
+__device__ constexpr double kC32[16] = {1.0, 0.9951847266721969, 0.9807852804032304, 0.9569403357322088, 0.9238795325112867, 0.881921264348355,
+                                        0.8314696123025452, 0.773010453362737, 0.7071067811865476, 0.6343932841636455, 0.5555702330196023,
+                                        0.4713967368259978, 0.38268343236508984, 0.29028467725446233, 0.19509032201612833, 0.09801714032956077};
+__device__ constexpr double kS32[16] = {0.0, 0.0980171403295606, 0.19509032201612825, 0.29028467725446233, 0.3826834323650898, 0.47139673682599764,
+                                        0.5555702330196022, 0.6343932841636455, 0.7071067811865475, 0.773010453362737, 0.8314696123025452,
+                                        0.8819212643483549, 0.9238795325112867, 0.9569403357322089, 0.9807852804032304, 0.9951847266721968};
+
+// 16 x 16 transpose inside each row of 16 lanes through the wave-private LDS buffer:
+// lane t writes element r to [g][r][t] and reads back [g][t][r].
+__device__ __forceinline__ void transpose16(double (&re)[16], double (&im)[16], c64 *tr, int g, int t) {
+    c64 *base = tr + g * kTrGroup;
+    wave_lds_fence();  // earlier reads of the aliased buffer are done
+#pragma unroll
+    for (int r = 0; r < 16; r++) base[r * kTrRow + t] = c64{re[r], im[r]};
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        c64 v = base[t * kTrRow + r];
+        re[r] = v.x;
+        im[r] = v.y;
+    }
+}
+
+// Forward negacyclic transform of one polynomial per row.  Input: the lane's 32 integer
+// coefficients (re = coefficient 16*n1 + t, im = coefficient 16*n1 + t + 256).  Output: lane k1 = t
+// holds frequency bins k1 + 16*k2, k2 = 0..15.
+__device__ __forceinline__ void fft_forward(double (&re)[16], double (&im)[16], const double (&twr)[16], const double (&twi)[16], c64 *tr, int g,
+                                            int t) {
+#pragma unroll
+    for (int n1 = 1; n1 < 16; n1++) cmulc<1>(re[n1], im[n1], kC32[n1], kS32[n1]);
+    dft16<1>(re, im);
+#pragma unroll
+    for (int k1 = 0; k1 < 16; k1++) cmulc<1>(re[k1], im[k1], twr[k1], twi[k1]);
+    transpose16(re, im, tr, g, t);
+    dft16<1>(re, im);
+}
+// Inverse of fft_forward without the 1/256 (folded into the Fourier key).
+__device__ __forceinline__ void fft_inverse(double (&re)[16], double (&im)[16], const double (&twr)[16], const double (&twi)[16], c64 *tr, int g,
+                                            int t) {
+    dft16<-1>(re, im);
+    transpose16(re, im, tr, g, t);
+#pragma unroll
+    for (int k1 = 0; k1 < 16; k1++) cmulc<-1>(re[k1], im[k1], twr[k1], twi[k1]);
+    dft16<-1>(re, im);
+#pragma unroll
+    for (int n1 = 1; n1 < 16; n1++) cmulc<-1>(re[n1], im[n1], kC32[n1], kS32[n1]);
+}
+
+// ---- cross-row reduction ---------------------------------------------------------------------
+// x[lanes 32..63] <-> y[lanes 0..31]
+__device__ __forceinline__ void swap_halves(double &x, double &y) {
+    uint2 a = __builtin_bit_cast(uint2, x), b = __builtin_bit_cast(uint2, y);
+    auto lo = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+    auto hi = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+    x = __builtin_bit_cast(double, uint2{lo[0], hi[0]});
+    y = __builtin_bit_cast(double, uint2{lo[1], hi[1]});
+}
+// x[odd rows] <-> y[even rows]
+__device__ __forceinline__ void swap_rows(double &x, double &y) {
+    uint2 a = __builtin_bit_cast(uint2, x), b = __builtin_bit_cast(uint2, y);
+    auto lo = __builtin_amdgcn_permlane16_swap(a.x, b.x, false, false);
+    auto hi = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
+    x = __builtin_bit_cast(double, uint2{lo[0], hi[0]});
+    y = __builtin_bit_cast(double, uint2{lo[1], hi[1]});
+}
+// Each row g holds partial sums p[c], c = 0..3; afterwards row g holds the total of p[g].
+__device__ __forceinline__ double reduce_scatter_rows(double p0, double p1, double p2, double p3) {
+    swap_halves(p0, p2);
+    swap_halves(p1, p3);
+    double sa = p0 + p2, sb = p1 + p3;
+    swap_rows(sa, sb);
+    return sa + sb;
+}
+
+// ---- integer helpers -------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t modswitch_2n(uint32_t x) {  // closest multiple of q/1024, index mod 1024
+    return (((x >> 21) + 1u) >> 1) & 1023u;
+}
+// signed decomposition, base 2^10, 2 levels: d1 pairs with q/2^10, d2 with q/2^20
+__device__ __forceinline__ void decompose2(uint32_t x, int &d1, int &d2) {
+    uint32_t state = (((x >> 11) + 1u) >> 1) & 0xFFFFFu;
+    uint32_t res = state & 1023u;
+    state >>= 10;
+    uint32_t carry = (((res - 1u) | state) & res) >> 9;
+    state += carry;
+    d2 = (int)res - (int)(carry << 10);
+    res = state & 1023u;
+    state >>= 10;
+    carry = (((res - 1u) | state) & res) >> 9;
+    d1 = (int)res - (int)(carry << 10);
+}
+__device__ __forceinline__ uint32_t round_torus(double x) {  // nearest integer mod 2^32, |x| < 2^62
+    x -= 4294967296.0 * __builtin_rint(x * (1.0 / 4294967296.0));
+    x += 6755399441055744.0;  // 1.5 * 2^52: low mantissa word = two's complement integer
+    return __builtin_bit_cast(uint2, x).x;
+}
+
+// bsk_f layout (c64): [i][level][k2][c][row g][t]  ->  the 64 lanes of a wave read 1 KiB contiguous
+__device__ __forceinline__ size_t bsk_index(uint32_t i, int lv, int k2, int c) { return ((((size_t)i * kLevels + lv) * 16 + k2) * kK1 + c) * 64; }
+
+// tw: [r][t] c64, e^{i pi t (1 + 4 r)/512}
+__global__ void __launch_bounds__(256, 1)
+    pbs_kernel(const uint32_t *__restrict__ in_base, uint32_t in_stride, const PbsJob *__restrict__ jobs, uint32_t n_jobs,
+               const c64 *__restrict__ bsk_f, const c64 *__restrict__ tw, uint32_t n, uint32_t steps, uint32_t *__restrict__ big_out,
+               uint32_t big_stride, uint32_t *__restrict__ acc_out) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, t = lane & 15;
+    const uint32_t job = blockIdx.x * kWavesPerBlock + wave;
+    if (job >= n_jobs) return;  // wave-uniform; the loop has no workgroup barrier
+    unsigned char *wl = lds + wave * (kWaveLdsBytes + kABytes);
+    c64 *tr = reinterpret_cast<c64 *>(wl);
+    uint32_t *rot = reinterpret_cast<uint32_t *>(wl);
+    uint16_t *a_tilde = reinterpret_cast<uint16_t *>(wl + kWaveLdsBytes);
+
+    // gate linear combination + modulus switch
+    const PbsJob jb = jobs[job];
+    const uint32_t *pa = in_base + (size_t)jb.a * in_stride, *pb = in_base + (size_t)jb.b * in_stride;
+    for (uint32_t idx = lane; idx <= n; idx += 64) {
+        uint32_t u = (uint32_t)jb.ca * pa[idx] + (uint32_t)jb.cb * pb[idx];
+        if (idx == n) u += jb.cst;
+        a_tilde[idx] = (uint16_t)modswitch_2n(u);
+    }
+    double twr[16], twi[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        c64 v = tw[r * 16 + t];
+        twr[r] = v.x;
+        twi[r] = v.y;
+    }
+    wave_lds_fence();
+    const uint32_t b_tilde = a_tilde[n];
+
+    // accumulator = X^{-b~} * (0, 0, 0, 2^29 * (1 + X + ... + X^{N-1}))
+    uint32_t acc[32];
+#pragma unroll
+    for (int m = 0; m < 32; m++) {
+        uint32_t jj = (uint32_t)(16 * m + t) + b_tilde;  // < 3N
+        acc[m] = (g == 3) ? (((jj >> 9) & 1u) ? 0xE0000000u : 0x20000000u) : 0u;
+    }
+
+    const uint32_t n_steps = steps < n ? steps : n;
+    for (uint32_t i = 0; i < n_steps; i++) {
+        const int a = __builtin_amdgcn_readfirstlane((int)a_tilde[i]);
+        if (a == 0) continue;  // X^0 - 1 = 0
+        // d = acc * X^a - acc through the rotation buffer, then signed decomposition
+        wave_lds_fence();
+#pragma unroll
+        for (int m = 0; m < 32; m++) rot[g * kRotStride + 16 * m + t] = acc[m];
+        wave_lds_fence();
+        uint32_t dig[32];  // level-1 digit in the low half, level-2 digit in the high half
+#pragma unroll
+        for (int m = 0; m < 32; m++) {
+            int jj = 16 * m + t - a;  // (-1024, 512)
+            uint32_t v = rot[g * kRotStride + (jj & 511)];
+            v = ((jj >> 9) & 1) ? 0u - v : v;
+            int d1, d2;
+            decompose2(v - acc[m], d1, d2);
+            dig[m] = ((uint32_t)d1 & 0xFFFFu) | ((uint32_t)d2 << 16);
+        }
+        // forward transforms of both digit levels
+        double f1r[16], f1i[16], f2r[16], f2i[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            f1r[q] = (double)((int)(dig[q] << 16) >> 16);
+            f1i[q] = (double)((int)(dig[q + 16] << 16) >> 16);
+            f2r[q] = (double)((int)dig[q] >> 16);
+            f2i[q] = (double)((int)dig[q + 16] >> 16);
+        }
+        fft_forward(f1r, f1i, twr, twi, tr, g, t);
+        fft_forward(f2r, f2i, twr, twi, tr, g, t);
+        // Fourier-domain multiply-accumulate: row g contributes polynomial g of both levels to all
+        // four output polynomials; the sum over rows lands in row c for output polynomial c.
+        double our[16], oui[16];
+        const c64 *bi = bsk_f + lane;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; k2++) {
+            double pr[4], pi[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                c64 b0 = bi[bsk_index(i, 0, k2, c)], b1 = bi[bsk_index(i, 1, k2, c)];
+                pr[c] = f1r[k2] * b0.x - f1i[k2] * b0.y + f2r[k2] * b1.x - f2i[k2] * b1.y;
+                pi[c] = f1r[k2] * b0.y + f1i[k2] * b0.x + f2r[k2] * b1.y + f2i[k2] * b1.x;
+            }
+            our[k2] = reduce_scatter_rows(pr[0], pr[1], pr[2], pr[3]);
+            oui[k2] = reduce_scatter_rows(pi[0], pi[1], pi[2], pi[3]);
+        }
+        fft_inverse(our, oui, twr, twi, tr, g, t);
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            acc[q] += round_torus(our[q]);
+            acc[q + 16] += round_torus(oui[q]);
+        }
+    }
+
+    if (acc_out) {  // raw accumulator [job][row][N]
+#pragma unroll
+        for (int m = 0; m < 32; m++) acc_out[((size_t)job * kK1 + g) * kN + 16 * m + t] = acc[m];
+        return;
+    }
+    // sample extraction of the constant coefficient: mask block r = (A_r[0], -A_r[N-1], ..., -A_r[1]), body B[0]
+    uint32_t *out = big_out + (size_t)job * big_stride;
+    if (g < 3) {
+#pragma unroll
+        for (int m = 0; m < 32; m++) {
+            int j = 16 * m + t;
+            out[g * kN + ((kN - j) & (kN - 1))] = j == 0 ? acc[m] : 0u - acc[m];
+        }
+    } else if (t == 0) {
+        out[3 * kN] = acc[0];
+    }
+}
+
+// Standard-domain GGSW rows -> Fourier layout.  One wave per GGSW row (i, level, r): its four
+// polynomials (columns c) are transformed together, row c of the wave taking column c.
+__global__ void __launch_bounds__(256, 1)
+    bsk_convert_kernel(const uint32_t *__restrict__ bsk, c64 *__restrict__ bsk_f, const c64 *__restrict__ tw, uint32_t n_rows) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, t = lane & 15;
+    const uint32_t row = blockIdx.x * kWavesPerBlock + wave;  // (i * l + lv) * 4 + r
+    if (row >= n_rows) return;
+    c64 *tr = reinterpret_cast<c64 *>(lds + wave * (kWaveLdsBytes + kABytes));
+    double twr[16], twi[16], re[16], im[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        c64 v = tw[r * 16 + t];
+        twr[r] = v.x;
+        twi[r] = v.y;
+    }
+    const uint32_t *src = bsk + ((size_t)row * kK1 + g) * kN;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        re[q] = (double)(int32_t)src[16 * q + t];
+        im[q] = (double)(int32_t)src[16 * q + t + 256];
+    }
+    fft_forward(re, im, twr, twi, tr, g, t);
+    const uint32_t r = row & 3, ilv = row >> 2;  // ilv = i * l + lv
+#pragma unroll
+    for (int k2 = 0; k2 < 16; k2++)
+        bsk_f[(((size_t)ilv * 16 + k2) * kK1 + g) * 64 + r * 16 + t] = c64{re[k2] * (1.0 / 256.0), im[k2] * (1.0 / 256.0)};
+}
+
+}  // namespace tfa
