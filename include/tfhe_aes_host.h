@@ -1,0 +1,93 @@
+/*
+ * tfhe_aes_host.h - C view of the host-side mirror of the reference's `base` and `modes` crates
+ * (FHEByte, State, Key, ECB/CBC/OFB/CTR, BooleanExpr::reduce_mux), for bindings and tests.
+ * The C++ classes themselves live in tfhe-aes_amd/host/ (namespace tfheaes); every function here
+ * forwards to the method of the same name and cites the reference method it mirrors.
+ *
+ * All functions return 0 on success or a negative code; tfh_last_error() returns the message of
+ * the calling thread's last failure.  Handles are owned by the caller and released with the
+ * matching *_free.  Gates are recorded lazily and executed in batched stages: tfh_flush(), any
+ * decrypt and any read force execution.
+ */
+#ifndef TFHE_AES_HOST_H
+#define TFHE_AES_HOST_H
+#include <stddef.h>
+#include <stdint.h>
+
+#include "tfhe_aes_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tfh_keys tfh_keys;   /* (ClientKey, ServerKey) of tfhe::boolean::gen_keys() */
+typedef struct tfh_ct tfh_ct;       /* tfhe::boolean::Ciphertext */
+typedef struct tfh_byte tfh_byte;   /* base::FHEByte   (primitive.rs:50-53) */
+typedef struct tfh_state tfh_state; /* base::State     (state.rs:9-12) */
+typedef struct tfh_key tfh_key;     /* base::Key       (key_schedule.rs:13-15) */
+
+const char *tfh_last_error(void);
+
+/* gen_keys() (main.rs:64); seed 0 = OS entropy.  The ServerKey lives on HIP device `device`. */
+int tfh_gen_keys(uint64_t seed, int device, tfh_keys **out);
+void tfh_keys_free(tfh_keys *k);
+tfa_ctx *tfh_context(tfh_keys *k);
+int tfh_flush(tfh_keys *k);
+int tfh_host_stats(tfh_keys *k, uint64_t out[4]); /* gates, stages, flushes, widest stage */
+int tfh_lwe_secret_key(tfh_keys *k, uint32_t *out /*[n]*/);
+
+/* Ciphertext-level gate API: ClientKey::{encrypt,decrypt}, ServerKey::{trivial_encrypt,and,...,mux,not} */
+int tfh_encrypt(tfh_keys *k, int message, tfh_ct **out);
+int tfh_trivial(tfh_keys *k, int message, tfh_ct **out);
+int tfh_decrypt(tfh_keys *k, const tfh_ct *ct, int *message);
+int tfh_gate(tfh_keys *k, uint32_t op /* enum tfa_op */, const tfh_ct *a, const tfh_ct *b, const tfh_ct *c, tfh_ct **out);
+int tfh_ct_is_trivial(const tfh_ct *ct);
+void tfh_ct_free(tfh_ct *ct);
+
+/* FHEByte (primitive.rs:55-368) */
+int tfh_byte_from_u8_enc(tfh_keys *k, uint8_t value, tfh_byte **out);
+int tfh_byte_from_u8_clear(tfh_keys *k, uint8_t value, tfh_byte **out);
+int tfh_byte_decrypt_to_u8(tfh_keys *k, const tfh_byte *b, uint8_t *out);
+int tfh_byte_binary(tfh_keys *k, uint32_t op /* TFA_XOR | TFA_AND | TFA_OR */, const tfh_byte *a, const tfh_byte *b, tfh_byte **out);
+int tfh_byte_not(tfh_keys *k, const tfh_byte *a, tfh_byte **out);
+int tfh_byte_sub_byte(tfh_keys *k, const tfh_byte *a, int inverse, tfh_byte **out);
+int tfh_byte_mul_x_gf2(tfh_keys *k, const tfh_byte *a, tfh_byte **out);
+void tfh_byte_free(tfh_byte *b);
+
+/* Key (key_schedule.rs:17-210) */
+int tfh_key_from_u8_enc(tfh_keys *k, const uint8_t key[16], tfh_key **out);
+int tfh_key_from_u8_clear(tfh_keys *k, const uint8_t key[16], tfh_key **out);
+int tfh_key_generate_round_keys(tfh_keys *k, const tfh_key *key, tfh_key *out[11]);
+int tfh_key_decrypt_to_u8(tfh_keys *k, const tfh_key *key, uint8_t out[16]);
+void tfh_key_free(tfh_key *key);
+int tfh_key_expansion_clear(const uint8_t key[16], uint8_t out[11][16]);
+
+/* State (state.rs:14-313) */
+enum tfh_state_op { TFH_SUB_BYTES = 0, TFH_INV_SUB_BYTES = 1, TFH_SHIFT_ROWS = 2, TFH_INV_SHIFT_ROWS = 3, TFH_MIX_COLUMNS = 4, TFH_INV_MIX_COLUMNS = 5 };
+int tfh_state_from_u8_enc(tfh_keys *k, const uint8_t data[16], tfh_state **out);
+int tfh_state_clone(const tfh_state *s, tfh_state **out);
+int tfh_state_apply(tfh_keys *k, tfh_state *s, uint32_t op /* enum tfh_state_op */);
+int tfh_state_xor_key_enc(tfh_keys *k, tfh_state *s, const tfh_key *key);
+int tfh_state_xor_key_clear(tfh_keys *k, tfh_state *s, const uint8_t key[16]);
+int tfh_state_xor_state(tfh_keys *k, tfh_state *s, const tfh_state *other);
+int tfh_state_decrypt_to_u8(tfh_keys *k, const tfh_state *s, uint8_t out[16]);
+/* the 128 LWE ciphertexts of a state ([16 bytes][8 bits, MSB first][n+1] words), for gathers */
+int tfh_state_read(tfh_keys *k, const tfh_state *s, uint32_t *out);
+int tfh_state_import(tfh_keys *k, const uint32_t *lwe, tfh_state **out);
+void tfh_state_free(tfh_state *s);
+
+/* Modes (modes/src/{ecb,cbc,ofb,ctr}.rs).  `states` are transformed in place; all n blocks are
+ * recorded before anything runs, so independent blocks share stages. */
+int tfh_ecb(tfh_keys *k, tfh_key *const round_keys[11], tfh_state *const *states, uint32_t n, int decrypt);
+int tfh_cbc(tfh_keys *k, tfh_key *const round_keys[11], const tfh_state *iv, tfh_state *const *states, uint32_t n, int decrypt);
+int tfh_ofb(tfh_keys *k, tfh_key *const round_keys[11], const tfh_state *iv, tfh_state *const *states, uint32_t n, int decrypt);
+int tfh_ctr(tfh_keys *k, tfh_key *const round_keys[11], tfh_state *const *counters, tfh_state *const *states, uint32_t n, int decrypt);
+
+/* Circuit layer (boolean_tree.rs:211-251, sbox.rs:53-61).  Text goes to `buf` (NUL terminated);
+ * returns the needed size when it does not fit. */
+long tfh_reduce_mux(const uint8_t *truth_table, uint32_t len, char *buf, size_t cap);
+long tfh_sbox_circuit_dump(int inverse, char *buf, size_t cap); /* one "stage<TAB>expr" line per node */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,189 @@
+"""The host mirror (FHEByte / State / Key / modes) on the HIP engine, written after the reference's
+own tests: /root/reference/base/src/primitive.rs:387-470, sbox.rs:113-166, state.rs:321-477,
+key_schedule.rs:220-246, modes/src/{ecb,cbc,ofb,ctr}.rs tests, plus the SP 800-38A vectors."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import boolean_tree_oracle as B
+from tfhe_aes_amd import host as H
+
+pytestmark = pytest.mark.gpu
+V = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "aes_vectors.json")))
+h = bytes.fromhex
+
+
+def test_gate_api_truth_tables_and_trivials(hkeys):
+    k = hkeys
+    e = {b: k.encrypt(b) for b in (False, True)}
+    t = {b: k.trivial_encrypt(b) for b in (False, True)}
+    fns = {"and": (k.and_, lambda a, b: a and b), "or": (k.or_, lambda a, b: a or b), "xor": (k.xor, lambda a, b: a != b),
+           "nand": (k.nand, lambda a, b: not (a and b)), "nor": (k.nor, lambda a, b: not (a or b)), "xnor": (k.xnor, lambda a, b: a == b)}
+    results = []
+    for name, (fn, clear) in fns.items():
+        for a in (False, True):
+            for b in (False, True):
+                results.append((fn(e[a], e[b]), clear(a, b)))
+                r = fn(e[a], t[b])  # a trivial operand never costs a bootstrap
+                results.append((r, clear(a, b)))
+                results.append((fn(t[a], t[b]), clear(a, b)))
+                assert fn(t[a], t[b]).is_trivial()
+    for c in (False, True):
+        for a in (False, True):
+            for b in (False, True):
+                results.append((k.mux(e[c], e[a], e[b]), a if c else b))
+                results.append((k.mux(e[c], t[a], e[b]), a if c else b))
+                results.append((k.mux(e[c], e[a], t[b]), a if c else b))
+                results.append((k.mux(t[c], e[a], e[b]), a if c else b))
+                results.append((k.mux(e[c], k.not_(e[a]), e[b]), (not a) if c else b))
+    before = k.host_stats()["gates"]
+    k.flush()
+    assert k.host_stats()["stages"] >= 1 and k.host_stats()["gates"] > before
+    for ct, exp in results:
+        assert k.decrypt(ct) == bool(exp)
+    assert k.decrypt(k.not_(e[True])) is False and k.decrypt(k.not_(t[False])) is True
+
+
+def test_xor_and_bytes(hkeys):  # primitive.rs:387-436
+    x, y = H.FHEByte.from_u8_enc(0b10101010, hkeys), H.FHEByte.from_u8_enc(0b11001100, hkeys)
+    assert x.xor(y).decrypt_to_u8() == 0b01100110
+    assert x.and_(y).decrypt_to_u8() == 0b10001000
+    assert x.or_(y).decrypt_to_u8() == 0b11101110
+    assert x.not_().decrypt_to_u8() == 0b01010101
+    assert x.xor(H.FHEByte.from_u8_clear(0xFF, hkeys)).decrypt_to_u8() == 0b01010101
+
+
+def test_sub_byte(hkeys):  # primitive.rs:438-452
+    x = H.FHEByte.from_u8_enc(0x01, hkeys)
+    before = hkeys.host_stats()
+    y = x.sub_byte()
+    assert y.decrypt_to_u8() == 0x7C
+    after = hkeys.host_stats()
+    assert after["gates"] - before["gates"] == 405 and after["stages"] - before["stages"] == 7
+    assert y.inv_sub_byte().decrypt_to_u8() == 0x01
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("inverse", [False, True])
+def test_all_sbox_values(hkeys, inverse):  # sbox.rs:113-166, all 256 inputs in one batched evaluation
+    table = B.INV_S_BOX if inverse else B.S_BOX
+    xs = [H.FHEByte.from_u8_enc(v, hkeys) for v in range(256)]
+    before = hkeys.host_stats()
+    ys = [x.inv_sub_byte() if inverse else x.sub_byte() for x in xs]
+    hkeys.flush()
+    after = hkeys.host_stats()
+    assert after["stages"] - before["stages"] == 7  # 256 bytes share the 7 stages
+    assert after["gates"] - before["gates"] == 256 * 405
+    assert [y.decrypt_to_u8() for y in ys] == list(table)
+
+
+def test_mul_gf_2_all_values(hkeys):  # primitive.rs:454-470
+    xs = [H.FHEByte.from_u8_enc(v, hkeys) for v in range(256)]
+    before = hkeys.host_stats()["gates"]
+    ys = [x.mul_x_gf2() for x in xs]
+    hkeys.flush()
+    assert hkeys.host_stats()["gates"] - before == 256 * 7  # 7 muxes per byte, the LSB is free
+    clear = lambda v: ((v << 1) ^ 0x1B) & 0xFF if v & 0x80 else (v << 1)
+    assert [y.decrypt_to_u8() for y in ys] == [clear(v) for v in range(256)]
+
+
+def test_state_round_functions(hkeys):  # state.rs:321-438, FIPS-197 Appendix B round 1
+    v = V["fips197_b"]
+    s = H.State.from_u128_enc(int(v["round1_start"], 16), hkeys)
+    assert s.decrypt_to_u8().hex() == v["round1_start"]
+    s.sub_bytes()
+    assert s.decrypt_to_u8().hex() == v["round1_sub_bytes"]
+    s.shift_rows()
+    assert s.decrypt_to_u8().hex() == v["round1_shift_rows"]
+    s.mix_columns()
+    assert s.decrypt_to_u8().hex() == v["round1_mix_columns"]
+    s.inv_mix_columns()
+    assert s.decrypt_to_u8().hex() == v["round1_shift_rows"]
+    s.inv_shift_rows()
+    assert s.decrypt_to_u8().hex() == v["round1_sub_bytes"]
+    s.inv_sub_bytes()
+    assert s.decrypt_to_u8().hex() == v["round1_start"]
+    s.xor_key_clear(h(v["key"]))
+    assert s.decrypt_to_u8() == bytes(a ^ b for a, b in zip(h(v["round1_start"]), h(v["key"])))
+    assert s.decrypt_to_u128() == int.from_bytes(s.decrypt_to_u8(), "big")
+
+
+@pytest.mark.timeout(300)
+def test_key_schedule_online(hkeys):  # key_schedule.rs:220-246 prints; here the round keys are asserted
+    key = h(V["fips197_b"]["key"])
+    rks = H.Key.from_u128_enc(int.from_bytes(key, "big"), hkeys).generate_round_keys()
+    expected = B.key_expansion_clear(key)
+    assert [rk.decrypt_to_u8() for rk in rks] == expected
+    assert expected[10].hex() == V["fips197_b"]["round_key_10"]
+    clear = H.Key.from_u8_clear(key, hkeys).generate_round_keys()  # trivial key: no bootstrap at all
+    assert [rk.decrypt_to_u8() for rk in clear] == expected
+
+
+def offline_round_keys(key, hkeys):
+    return [H.Key.from_u8_enc(rk, hkeys) for rk in H.key_expansion_clear(key)]
+
+
+@pytest.mark.timeout(300)
+def test_ecb_once(hkeys):  # modes/src/ecb.rs:62-89, FIPS-197 Appendix B
+    v = V["fips197_b"]
+    ecb = H.ECB(offline_round_keys(h(v["key"]), hkeys))
+    state = H.State.from_u128_enc(int(v["plaintext"], 16), hkeys)
+    before = hkeys.host_stats()
+    ecb.encrypt(state)
+    assert state.decrypt_to_u128() == int(v["ciphertext"], 16)
+    after = hkeys.host_stats()
+    assert after["gates"] - before["gates"] == 71824
+    ecb.decrypt(state)
+    assert state.decrypt_to_u128() == int(v["plaintext"], 16)
+
+
+@pytest.mark.timeout(300)
+def test_ecb_twice_same_result(hkeys):  # modes/src/ecb.rs:91-114
+    v = V["fips197_c1"]
+    ecb = H.ECB(offline_round_keys(h(v["key"]), hkeys))
+    s0 = H.State.from_u8_enc(h(v["plaintext"]), hkeys)
+    s1 = s0.clone()
+    ecb.encrypt_many([s0, s1])
+    assert s0.decrypt_to_u8().hex() == s1.decrypt_to_u8().hex() == v["ciphertext"]
+
+
+@pytest.mark.timeout(600)
+def test_sp800_38a_cbc_ofb_ctr(hkeys):  # modes/src/{cbc,ofb,ctr}.rs tests + NIST known answers
+    v = V["sp800_38a"]
+    rk = offline_round_keys(h(v["key"]), hkeys)
+    mk = lambda: [H.State.from_u8_enc(h(p), hkeys) for p in v["plaintext"]]
+    iv = H.State.from_u8_enc(h(v["iv"]), hkeys)
+    blocks = mk()
+    cbc = H.CBC(rk, iv, 4)
+    cbc.encrypt(blocks)
+    assert [b.decrypt_to_u8().hex() for b in blocks] == v["cbc"]
+    cbc.decrypt(blocks)
+    assert [b.decrypt_to_u8().hex() for b in blocks] == v["plaintext"]
+    blocks = mk()
+    ofb = H.OFB(rk, iv, 4)
+    ofb.encrypt(blocks)
+    assert [b.decrypt_to_u8().hex() for b in blocks] == v["ofb"]
+    ofb.decrypt(blocks)
+    assert [b.decrypt_to_u8().hex() for b in blocks] == v["plaintext"]
+    c0 = int(v["ctr_init"], 16)
+    counters = [H.State.from_u128_enc((c0 + i) % (1 << 128), hkeys) for i in range(4)]
+    blocks = mk()
+    ctr = H.CTR(rk, counters, 4)
+    ctr.encrypt(blocks)
+    assert [b.decrypt_to_u8().hex() for b in blocks] == v["ctr"]
+    ctr.decrypt(blocks)
+    assert [b.decrypt_to_u8().hex() for b in blocks] == v["plaintext"]
+    with pytest.raises(H.HostError):
+        H.CTR(rk, counters[:3], 4)
+
+
+def test_state_read_import_roundtrip(hkeys):
+    data = bytes(range(16))
+    s = H.State.from_u8_enc(data, hkeys)
+    s.xor_key_clear(bytes([0xFF] * 16))
+    lwe = s.read()
+    assert lwe.shape == (128, hkeys.params.lwe_dimension + 1)
+    t = H.State.import_lwe(lwe, hkeys)
+    assert t.decrypt_to_u8() == bytes(b ^ 0xFF for b in data)

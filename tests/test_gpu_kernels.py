@@ -1,0 +1,204 @@
+"""Parity of the HIP kernels with the CPU oracle, through the C ABI (ctypes), on cuda:0.
+Integer stages (gate combination, modulus switch, rotation, decomposition, sample extract,
+keyswitch) must be bit-exact.  The blind rotation runs an fp64 FFT: its products are rounded to
+integers and the rounding error of the transform stays far below 1/2, so its outputs are expected
+to be bit-identical to the exact-integer oracle too; the hard bound asserted is the FFT noise
+bound below, and the number of bit-identical results is asserted to be nearly all of them."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as P
+from tfhe_aes_amd import engine as E
+
+pytestmark = pytest.mark.gpu
+
+# |phase(gpu) - phase(exact oracle)| allowed on a bootstrap output, in torus units of 2^-32.  One
+# flipped decomposition digit moves the phase by about 2^12; the blind-rotation noise itself has a
+# standard deviation of about 2^21, so 2^16 is the "FFT noise bound": far below the scheme's noise.
+FFT_NOISE_BOUND = 1 << 16
+
+
+def sdiff(a, b):
+    return (a.astype(np.int64) - b.astype(np.int64) + 2**31) % 2**32 - 2**31
+
+
+def test_keyswitch_bit_exact(gpu_ctx, oracle, okeys):
+    rng = np.random.default_rng(1)
+    big = rng.integers(0, 2**32, (37, gpu_ctx.big + 1), dtype=np.uint64).astype(np.uint32)
+    big[0] = 0
+    big[1] = 0xFFFFFFFF
+    big[2] = 0x80000000
+    big[3] = 0x00010000  # exactly half of the last representable step: exercises the rounding tie
+    got = gpu_ctx.keyswitch_batch(big)
+    ref = np.stack([oracle.keyswitch(okeys[3], b) for b in big])
+    assert (got == ref).all()
+
+
+def test_keyswitch_tile_sizes_bit_exact(gpu_ctx, oracle, okeys):
+    """Every tile width of the keyswitch kernel (batches of 1, 1100 and 8200 gates)."""
+    rng = np.random.default_rng(2)
+    for count in (1, 1100, 8200):
+        big = rng.integers(0, 2**32, (count, gpu_ctx.big + 1), dtype=np.uint64).astype(np.uint32)
+        got = gpu_ctx.keyswitch_batch(big)
+        for i in (0, count // 2, count - 1):
+            assert (got[i] == oracle.keyswitch(okeys[3], big[i])).all()
+        # linearity in the body: the mask part does not depend on b
+        big2 = big[:1].copy()
+        big2[0, -1] += 12345
+        assert (sdiff(gpu_ctx.keyswitch_batch(big2)[0], got[0])[:-1] == 0).all()
+
+
+def test_blind_rotation_prefix_bit_exact(gpu_ctx, oracle, okeys):
+    """Accumulator after 0, 1, 2 and 9 external products against the exact-integer oracle."""
+    cts = oracle.encrypt_bits(okeys[0], 77, 0, np.array([0, 1, 1], np.uint8))
+    cts[2, 5] = 0  # a mask word that modulus-switches to 0: the skipped-iteration path
+    for steps in (0, 1, 2, 9):
+        got = gpu_ctx.blind_rotate_batch(cts, steps)
+        for g in range(3):
+            ref = oracle.blind_rotate(okeys[2], None, cts[g], steps)
+            assert np.abs(sdiff(got[g], ref)).max() <= 1, (steps, g)
+            assert (got[g] == ref).mean() > 0.999
+
+
+def test_bootstrap_against_exact_oracle(gpu_ctx, oracle, okeys):
+    lwe_sk, glwe_sk, bsk, ksk = okeys
+    bits = np.array([0, 1], np.uint8)
+    cts = oracle.encrypt_bits(lwe_sk, 78, 0, bits)
+    got = gpu_ctx.bootstrap_batch(cts)
+    for g in range(2):
+        ref = oracle.pbs(bsk, None, cts[g])
+        d = (oracle.phase(glwe_sk, got[g]) - oracle.phase(glwe_sk, ref) + 2**31) % 2**32 - 2**31
+        assert abs(d) <= FFT_NOISE_BOUND
+        assert (got[g] == ref).all(), "expected bit-identical to the exact engine"
+        assert (oracle.phase(glwe_sk, got[g]) < 2**31) == bool(bits[g])
+
+
+def test_bootstrap_batch_against_fft_oracle(gpu_ctx, oracle, okeys, obsk_f):
+    lwe_sk, glwe_sk, bsk, ksk = okeys
+    bits = np.random.default_rng(9).integers(0, 2, 48).astype(np.uint8)
+    cts = oracle.encrypt_bits(lwe_sk, 79, 0, bits)
+    got = gpu_ctx.bootstrap_batch(cts)
+    identical = 0
+    for g in range(48):
+        ref = oracle.pbs(bsk, obsk_f, cts[g])
+        d = (oracle.phase(glwe_sk, got[g]) - oracle.phase(glwe_sk, ref) + 2**31) % 2**32 - 2**31
+        assert abs(d) <= FFT_NOISE_BOUND
+        identical += int((got[g] == ref).all())
+        # refreshed noise: the output sits within 2^-6 of +-1/8
+        ph = oracle.phase(glwe_sk, got[g])
+        centre = (1 << 29) if bits[g] else (7 << 29)
+        assert abs((ph - centre + 2**31) % 2**32 - 2**31) < 2**26
+    assert identical >= 46
+
+
+def clear_gate(op, a, b, c):
+    return np.select([op == 0, op == 1, op == 2, op == 3, op == 4, op == 5, op == 6],
+                     [a & b, 1 - (a & b), a | b, 1 - (a | b), a ^ b, 1 - (a ^ b), np.where(a == 1, b, c)]).astype(np.uint8)
+
+
+def test_mixed_gates_with_negations(gpu_ctx, oracle, okeys, obsk_f):
+    lwe_sk, _, bsk, ksk = okeys
+    G = 2048
+    rng = np.random.default_rng(10)
+    a, b, c = (rng.integers(0, 2, G).astype(np.uint8) for _ in range(3))
+    ca, cb, cc = (oracle.encrypt_bits(lwe_sk, 80, s, x) for s, x in enumerate((a, b, c)))
+    gpu_ctx.pool_reserve(4 * G)
+    gpu_ctx.pool_write(np.arange(G), ca)
+    gpu_ctx.pool_write(np.arange(G, 2 * G), cb)
+    gpu_ctx.pool_write(np.arange(2 * G, 3 * G), cc)
+    ops, neg = rng.integers(0, 7, G), rng.integers(0, 8, G)
+    gpu_ctx.stage_submit(E.make_gates(ops, np.arange(G), np.arange(G, 2 * G), np.arange(2 * G, 3 * G), np.arange(3 * G, 4 * G), neg))
+    gpu_ctx.sync()
+    out = gpu_ctx.pool_read(np.arange(3 * G, 4 * G))
+    exp = clear_gate(ops, a ^ (neg & 1), b ^ ((neg >> 1) & 1), c ^ ((neg >> 2) & 1))
+    assert (oracle.decrypt_bits(lwe_sk, out) == exp).all()
+    # word-for-word against the oracle on a sample (negation = LWE negation of the operand)
+    idx = np.arange(0, G, G // 24)[:24]
+    flip = lambda ct, m: np.where(m[:, None] == 1, (0 - ct.astype(np.int64)) % 2**32, ct).astype(np.uint32)
+    ref = oracle.gates(bsk, obsk_f, ksk, ops[idx].astype(np.uint8), flip(ca[idx], neg[idx] & 1), flip(cb[idx], (neg[idx] >> 1) & 1),
+                       flip(cc[idx], (neg[idx] >> 2) & 1))
+    same = (ref == out[idx]).all(axis=1)
+    assert same.sum() >= 22
+    for i in np.nonzero(~same)[0]:
+        d = (oracle.phase(lwe_sk, ref[i]) - oracle.phase(lwe_sk, out[idx[i]]) + 2**31) % 2**32 - 2**31
+        assert abs(d) <= 64 * FFT_NOISE_BOUND
+
+
+def test_not_copy_and_chained_stages(gpu_ctx, oracle, okeys):
+    lwe_sk = okeys[0]
+    bits = np.array([1, 0, 1, 1], np.uint8)
+    gpu_ctx.pool_reserve(64)
+    gpu_ctx.pool_write(np.arange(4), oracle.encrypt_bits(lwe_sk, 81, 0, bits))
+    g1 = E.make_gates([E.NOT, E.COPY, E.XOR], [0, 1, 2], [0, 0, 3], None, [10, 11, 12])
+    g2 = E.make_gates([E.AND, E.MUX], [10, 12], [11, 10], [0, 11], [20, 21])  # stage 2 consumes stage 1
+    gpu_ctx.stage_submit(g1)
+    gpu_ctx.stage_submit(g2)
+    gpu_ctx.sync()
+    got = oracle.decrypt_bits(lwe_sk, gpu_ctx.pool_read([10, 11, 12, 20, 21]))
+    n0, c1, x23 = 1 - bits[0], bits[1], bits[2] ^ bits[3]
+    assert list(got) == [n0, c1, x23, n0 & c1, (n0 if x23 else c1)]
+    raw = gpu_ctx.pool_read([0, 10])
+    assert (raw[1] == (0 - raw[0].astype(np.int64)) % 2**32).all()  # NOT is an exact LWE negation
+
+
+def test_error_paths(gpu_ctx, okeys):
+    lib = E.load_library()
+    fresh = E.Context(E.default_params(), 0)
+    g = E.make_gates([E.AND], [0], [1], None, [2])
+    with pytest.raises(E.TfaError, match="before tfa_keys_upload"):
+        fresh.stage_submit(g)
+    fresh.close()
+    gpu_ctx.pool_reserve(16)
+    bad = E.make_gates([E.AND], [0], [1], None, [2**31])
+    with pytest.raises(E.TfaError, match="out of range"):
+        gpu_ctx.stage_submit(bad)
+    with pytest.raises(E.TfaError, match="opcode"):
+        gpu_ctx.stage_submit(E.make_gates([99], [0], [1], None, [2]))
+    gpu_ctx.stage_submit(np.zeros(0, E.GATE_DTYPE))  # empty stage is a no-op
+    assert gpu_ctx.pool_read(np.zeros(0, np.uint32)).shape == (0, gpu_ctx.n + 1)
+    assert lib.tfa_pool_write(gpu_ctx._ctx, None, 0, None) == -1
+
+
+@pytest.mark.timeout(300)
+def test_config2_65536_nand_xor_gates(gpu_ctx, oracle, okeys):
+    """BASELINE config 2: 65536 independent NAND/XOR gates of fresh encryptions, one stage submit."""
+    lwe_sk = okeys[0]
+    G = 65536
+    bits = np.random.default_rng(11).integers(0, 2, 2 * G).astype(np.uint8)
+    cts = E.client_encrypt(E.default_params(), lwe_sk, 4242, bits)
+    gpu_ctx.pool_reserve(3 * G)
+    gpu_ctx.pool_write(np.arange(2 * G), cts)
+    even = np.arange(G) % 2 == 0
+    gpu_ctx.stage_submit(E.make_gates(np.where(even, E.NAND, E.XOR), np.arange(G), np.arange(G, 2 * G), None, np.arange(2 * G, 3 * G)))
+    gpu_ctx.sync()
+    got = oracle.decrypt_bits(lwe_sk, gpu_ctx.pool_read(np.arange(2 * G, 3 * G)))
+    x, y = bits[:G], bits[G:]
+    assert (got == np.where(even, 1 - (x & y), x ^ y)).all()
+
+
+@pytest.mark.timeout(600)
+def test_zero_decryption_failures_over_a_million_gates(gpu_ctx, oracle, okeys):
+    """16 x 65536 gates, each round feeding on the previous round's outputs (so bootstrapped, not
+    only fresh, noise is exercised); every one of the 1,048,576 results must decrypt correctly."""
+    lwe_sk = okeys[0]
+    G = 65536
+    rng = np.random.default_rng(12)
+    bits = rng.integers(0, 2, 2 * G).astype(np.uint8)
+    gpu_ctx.pool_reserve(3 * G)
+    gpu_ctx.pool_write(np.arange(2 * G), E.client_encrypt(E.default_params(), lwe_sk, 4343, bits))
+    x, y = bits[:G].copy(), bits[G:].copy()
+    failures = 0
+    src_a, src_b, dst = 0, G, 2 * G
+    for rnd in range(16):
+        ops = rng.integers(0, 6, G)
+        perm = rng.permutation(G)
+        gpu_ctx.stage_submit(E.make_gates(ops, src_a + np.arange(G), src_b + perm, None, dst + np.arange(G)))
+        gpu_ctx.sync()
+        exp = clear_gate(ops, x, y[perm], y)
+        got = oracle.decrypt_bits(lwe_sk, gpu_ctx.pool_read(dst + np.arange(G)))
+        failures += int((got != exp).sum())
+        x, y = exp, x  # next round: a = this output, b = previous a
+        src_a, src_b, dst = dst, src_a, src_b
+    assert failures == 0

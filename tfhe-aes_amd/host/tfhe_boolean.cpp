@@ -1,0 +1,272 @@
+#include "tfhe_boolean.h"
+
+#include <algorithm>
+#include <stdexcept>
+
+namespace tfheaes {
+
+namespace detail {
+struct SlotRef {
+    ServerKey *owner;
+    std::weak_ptr<int> alive;
+    uint32_t slot;
+    uint32_t level;
+    uint64_t epoch;
+    SlotRef(ServerKey *o, const std::shared_ptr<int> &a, uint32_t s, uint32_t l, uint64_t e) : owner(o), alive(a), slot(s), level(l), epoch(e) {}
+    SlotRef(const SlotRef &) = delete;  // exactly one owner per slot: a copy would release it twice
+    SlotRef &operator=(const SlotRef &) = delete;
+    ~SlotRef() {
+        if (!alive.expired()) owner->release_slot(slot);
+    }
+};
+struct Enc {
+    std::vector<uint32_t> words;    // n+1 host words while not yet on a device
+    std::shared_ptr<SlotRef> slot;  // set on first use by a ServerKey
+};
+}  // namespace detail
+
+static void check(tfa_ctx *ctx, int rc, const char *what) {
+    if (rc != TFA_OK) throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " + tfa_last_error(ctx));
+}
+
+Ciphertext Ciphertext::trivial(bool v) {
+    Ciphertext c;
+    c.kind_ = Kind::Trivial;
+    c.value_ = v;
+    return c;
+}
+
+// ---------------------------------------------------------------------------------------------
+ClientKey::ClientKey(const tfa_params &p, uint64_t seed, std::vector<uint32_t> lwe_sk, std::vector<uint32_t> glwe_sk)
+    : p_(p), enc_seed_(seed ? seed * 0x9E3779B97F4A7C15ull + 0x7F4A7C15ull : 0), lwe_sk_(std::move(lwe_sk)), glwe_sk_(std::move(glwe_sk)) {}
+
+Ciphertext ClientKey::encrypt(bool message) const {
+    Ciphertext c;
+    c.kind_ = Ciphertext::Kind::Encrypted;
+    c.enc_ = std::make_shared<detail::Enc>();
+    c.enc_->words.resize(p_.lwe_dimension + 1);
+    uint8_t bit = message ? 1 : 0;
+    // a fresh stream per ciphertext; seed 0 (OS entropy) stays 0 so every call draws anew
+    uint64_t s = enc_seed_ ? enc_seed_ + (++enc_counter_) * 0xD1B54A32D192ED03ull : 0;
+    if (enc_seed_ && s == 0) s = 1;
+    int rc = tfa_client_encrypt(&p_, lwe_sk_.data(), s, &bit, 1, c.enc_->words.data());
+    if (rc != TFA_OK) throw std::runtime_error("tfa_client_encrypt failed");
+    return c;
+}
+
+bool ClientKey::decrypt(const Ciphertext &ct) const {
+    if (ct.kind_ == Ciphertext::Kind::Trivial) return ct.value_;
+    if (ct.kind_ == Ciphertext::Kind::Empty) throw std::invalid_argument("decrypt of an empty ciphertext");
+    std::vector<uint32_t> words;
+    if (!ct.enc_->slot) {
+        words = ct.enc_->words;
+        if (ct.neg_)
+            for (auto &w : words) w = 0u - w;
+    } else {
+        words = ct.enc_->slot->owner->read(ct);
+    }
+    uint8_t bit = 0;
+    if (tfa_client_decrypt(&p_, lwe_sk_.data(), words.data(), 1, &bit) != TFA_OK) throw std::runtime_error("tfa_client_decrypt failed");
+    return bit != 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+ServerKey::ServerKey(const tfa_params &p, const uint32_t *bsk, const uint32_t *ksk, int device) : p_(p), alive_(std::make_shared<int>(0)) {
+    int rc = tfa_ctx_create(&p_, device, &ctx_);
+    if (rc != TFA_OK) {
+        std::string msg = ctx_ ? tfa_last_error(ctx_) : "invalid parameters or device";
+        if (ctx_) tfa_ctx_destroy(ctx_);
+        ctx_ = nullptr;
+        throw std::runtime_error("tfa_ctx_create failed (" + std::to_string(rc) + "): " + msg);
+    }
+    rc = tfa_keys_upload(ctx_, bsk, ksk);
+    if (rc != TFA_OK) {
+        std::string msg = tfa_last_error(ctx_);
+        tfa_ctx_destroy(ctx_);
+        ctx_ = nullptr;
+        throw std::runtime_error("tfa_keys_upload failed: " + msg);
+    }
+    pool_slots_ = 1u << 14;
+    check(ctx_, tfa_pool_reserve(ctx_, pool_slots_), "tfa_pool_reserve");
+}
+
+ServerKey::~ServerKey() {
+    alive_.reset();  // outstanding handles stop calling back
+    if (ctx_) tfa_ctx_destroy(ctx_);
+}
+
+uint32_t ServerKey::alloc_slot() {
+    if (!free_.empty()) {
+        uint32_t s = free_.back();
+        free_.pop_back();
+        return s;
+    }
+    if (next_fresh_ == pool_slots_) {
+        uint64_t grown = (uint64_t)pool_slots_ * 2;
+        if (grown > 0xFFFFFFF0ull) throw std::runtime_error("ciphertext pool exhausted");
+        check(ctx_, tfa_pool_reserve(ctx_, (uint32_t)grown), "tfa_pool_reserve");
+        pool_slots_ = (uint32_t)grown;
+    }
+    return next_fresh_++;
+}
+
+// A released slot may still be read by recorded, not yet submitted gates: recycle it after the flush.
+void ServerKey::release_slot(uint32_t slot) { deferred_free_.push_back(slot); }
+
+ServerKey::Resolved ServerKey::resolve(const Ciphertext &ct) {
+    if (ct.kind_ != Ciphertext::Kind::Encrypted) throw std::invalid_argument("gate operand is not an encrypted ciphertext");
+    detail::Enc &e = *ct.enc_;
+    if (!e.slot) {
+        // first use on the device: give it a slot and queue the upload (seen by all copies of the handle)
+        e.slot = std::make_shared<detail::SlotRef>(this, alive_, alloc_slot(), 0u, epoch_);
+        upload_slots_.push_back(e.slot->slot);
+        upload_words_.insert(upload_words_.end(), e.words.begin(), e.words.end());
+        e.words.clear();
+        e.words.shrink_to_fit();
+    }
+    if (e.slot->owner != this) throw std::invalid_argument("ciphertext belongs to another ServerKey");
+    uint32_t lvl = e.slot->epoch == epoch_ ? e.slot->level : 0;
+    return Resolved{e.slot->slot, lvl, ct.neg_};
+}
+
+Ciphertext ServerKey::record(uint32_t op, const Resolved *in, int n_in) {
+    uint32_t lvl = 0, neg = 0;
+    for (int i = 0; i < n_in; i++) {
+        lvl = std::max(lvl, in[i].level);
+        if (in[i].neg) neg |= 1u << i;
+    }
+    lvl += 1;
+    auto ref = std::make_shared<detail::SlotRef>(this, alive_, alloc_slot(), lvl, epoch_);
+    tfa_gate g{op, in[0].slot, n_in > 1 ? in[1].slot : 0u, n_in > 2 ? in[2].slot : 0u, ref->slot, neg};
+    if (levels_.size() < lvl) levels_.resize(lvl);
+    levels_[lvl - 1].push_back(g);
+    pending_count_++;
+    Ciphertext c;
+    c.kind_ = Ciphertext::Kind::Encrypted;
+    c.enc_ = std::make_shared<detail::Enc>();
+    c.enc_->slot = std::move(ref);
+    return c;
+}
+
+Ciphertext ServerKey::not_(const Ciphertext &a) const {
+    Ciphertext c = a;
+    if (c.kind_ == Ciphertext::Kind::Trivial)
+        c.value_ = !c.value_;
+    else if (c.kind_ == Ciphertext::Kind::Empty)
+        throw std::invalid_argument("not of an empty ciphertext");
+    else
+        c.neg_ = !c.neg_;  // LWE negation is free: folded into the consumer's linear combination
+    return c;
+}
+
+// Binary gates with tfhe-rs' treatment of trivial operands (a trivial operand never costs a bootstrap).
+Ciphertext ServerKey::binary(uint32_t op, const Ciphertext &a, const Ciphertext &b) {
+    const bool ta = a.is_trivial(), tb = b.is_trivial();
+    if (ta && tb) {
+        bool x = a.value_, y = b.value_, r = false;
+        switch (op) {
+        case TFA_AND: r = x && y; break;
+        case TFA_NAND: r = !(x && y); break;
+        case TFA_OR: r = x || y; break;
+        case TFA_NOR: r = !(x || y); break;
+        case TFA_XOR: r = x != y; break;
+        default: r = x == y; break;
+        }
+        return Ciphertext::trivial(r);
+    }
+    if (ta || tb) {
+        const Ciphertext &e = ta ? b : a;
+        const bool t = ta ? a.value_ : b.value_;
+        switch (op) {
+        case TFA_AND: return t ? e : Ciphertext::trivial(false);
+        case TFA_NAND: return t ? not_(e) : Ciphertext::trivial(true);
+        case TFA_OR: return t ? Ciphertext::trivial(true) : e;
+        case TFA_NOR: return t ? Ciphertext::trivial(false) : not_(e);
+        case TFA_XOR: return t ? not_(e) : e;
+        default: return t ? e : not_(e);
+        }
+    }
+    Resolved in[2] = {resolve(a), resolve(b)};
+    return record(op, in, 2);
+}
+Ciphertext ServerKey::and_(const Ciphertext &a, const Ciphertext &b) { return binary(TFA_AND, a, b); }
+Ciphertext ServerKey::nand(const Ciphertext &a, const Ciphertext &b) { return binary(TFA_NAND, a, b); }
+Ciphertext ServerKey::or_(const Ciphertext &a, const Ciphertext &b) { return binary(TFA_OR, a, b); }
+Ciphertext ServerKey::nor(const Ciphertext &a, const Ciphertext &b) { return binary(TFA_NOR, a, b); }
+Ciphertext ServerKey::xor_(const Ciphertext &a, const Ciphertext &b) { return binary(TFA_XOR, a, b); }
+Ciphertext ServerKey::xnor(const Ciphertext &a, const Ciphertext &b) { return binary(TFA_XNOR, a, b); }
+
+Ciphertext ServerKey::mux(const Ciphertext &cond, const Ciphertext &then_ct, const Ciphertext &else_ct) {
+    if (cond.is_trivial()) return cond.value_ ? then_ct : else_ct;
+    if (then_ct.is_trivial()) return then_ct.value_ ? or_(cond, else_ct) : and_(not_(cond), else_ct);
+    if (else_ct.is_trivial()) return else_ct.value_ ? or_(then_ct, not_(cond)) : and_(cond, then_ct);
+    Resolved in[3] = {resolve(cond), resolve(then_ct), resolve(else_ct)};
+    return record(TFA_MUX, in, 3);
+}
+
+void ServerKey::upload_pending() {
+    if (upload_slots_.empty()) return;
+    check(ctx_, tfa_pool_write(ctx_, upload_slots_.data(), (uint32_t)upload_slots_.size(), upload_words_.data()), "tfa_pool_write");
+    upload_slots_.clear();
+    upload_words_.clear();
+}
+
+void ServerKey::flush() {
+    upload_pending();
+    for (auto &lv : levels_) {
+        if (lv.empty()) continue;
+        check(ctx_, tfa_stage_submit(ctx_, lv.data(), (uint32_t)lv.size()), "tfa_stage_submit");
+        stats_.gates += lv.size();
+        stats_.stages++;
+        stats_.max_stage_width = std::max<uint64_t>(stats_.max_stage_width, lv.size());
+    }
+    check(ctx_, tfa_sync(ctx_), "tfa_sync");
+    levels_.clear();
+    pending_count_ = 0;
+    epoch_++;
+    stats_.flushes++;
+    free_.insert(free_.end(), deferred_free_.begin(), deferred_free_.end());
+    deferred_free_.clear();
+}
+
+void ServerKey::read_many(const std::vector<const Ciphertext *> &cts, uint32_t *out) {
+    const uint32_t words = p_.lwe_dimension + 1;
+    std::vector<uint32_t> slots;
+    std::vector<Resolved> res;
+    for (auto *c : cts) res.push_back(resolve(*c));
+    flush();
+    for (auto &r : res) slots.push_back(r.slot);
+    if (!slots.empty()) check(ctx_, tfa_pool_read(ctx_, slots.data(), (uint32_t)slots.size(), out), "tfa_pool_read");
+    for (size_t i = 0; i < res.size(); i++)
+        if (res[i].neg)
+            for (uint32_t w = 0; w < words; w++) out[i * words + w] = 0u - out[i * words + w];
+}
+
+std::vector<uint32_t> ServerKey::read(const Ciphertext &ct) {
+    std::vector<uint32_t> out(p_.lwe_dimension + 1);
+    read_many({&ct}, out.data());
+    return out;
+}
+
+Ciphertext ServerKey::import_lwe(const uint32_t *lwe) {
+    Ciphertext c;
+    c.kind_ = Ciphertext::Kind::Encrypted;
+    c.enc_ = std::make_shared<detail::Enc>();
+    c.enc_->words.assign(lwe, lwe + p_.lwe_dimension + 1);
+    return c;
+}
+
+KeyPair gen_keys(uint64_t seed, int device) {
+    tfa_params p;
+    tfa_default_params(&p);
+    std::vector<uint32_t> lwe_sk(p.lwe_dimension), glwe_sk((size_t)p.glwe_dimension * p.polynomial_size);
+    std::vector<uint32_t> bsk(tfa_bsk_words(&p)), ksk(tfa_ksk_words(&p));
+    if (tfa_client_keygen(&p, seed, lwe_sk.data(), glwe_sk.data(), bsk.data(), ksk.data()) != TFA_OK)
+        throw std::runtime_error("tfa_client_keygen failed");
+    KeyPair kp;
+    kp.server = std::make_unique<ServerKey>(p, bsk.data(), ksk.data(), device);
+    kp.client = std::make_unique<ClientKey>(p, seed, std::move(lwe_sk), std::move(glwe_sk));
+    return kp;
+}
+
+}  // namespace tfheaes
