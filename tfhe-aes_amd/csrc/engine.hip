@@ -188,7 +188,7 @@ extern "C" int tfa_ctx_create(const tfa_params *p, int hip_device, tfa_ctx **out
     HIPCHK(ctx, hipMalloc(&ctx->d_tw, sizeof(c64) * 256));
     HIPCHK(ctx, hipMemcpy(ctx->d_tw, tw.data(), sizeof(c64) * 256, hipMemcpyHostToDevice));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kPbsLdsBytes));
-    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bsk_convert_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kPbsLdsBytes));
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bsk_convert_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kConvertLdsBytes));
     return TFA_OK;
 }
 
@@ -237,7 +237,7 @@ extern "C" int tfa_keys_upload(tfa_ctx *ctx, const uint32_t *bsk, const uint32_t
     hipError_t e = hipMemcpy(d_std, bsk, bsk_words * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         const uint32_t rows = n * p.pbs_level * (p.glwe_dimension + 1);
-        hipLaunchKernelGGL(bsk_convert_kernel, dim3((rows + kWavesPerBlock - 1) / kWavesPerBlock), dim3(256), kPbsLdsBytes, ctx->stream, d_std,
+        hipLaunchKernelGGL(bsk_convert_kernel, dim3((rows + kWavesPerBlock - 1) / kWavesPerBlock), dim3(256), kConvertLdsBytes, ctx->stream, d_std,
                            ctx->d_bsk_f, ctx->d_tw, rows);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

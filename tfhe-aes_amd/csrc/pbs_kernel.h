@@ -7,7 +7,8 @@
 // size-512 transform is a size-256 complex FFT computed as 16 x 16: a register-resident DFT16 per
 // lane, one 16 x 16 transpose through wave-private LDS, a second register DFT16.  The Fourier
 // domain multiply-accumulate with the bootstrapping key sums over the four rows with the gfx950
-// row/half swap instructions, so no workgroup barrier is needed anywhere in the loop.
+// row/half swap instructions.  The four waves of a workgroup advance in lock step and share the
+// bootstrapping key through an LDS ring filled by LDS-DMA, one barrier per 16 KiB chunk.
 //
 // What the kernel computes follows tfhe-rs 0.11 (blind_rotate_assign / add_external_product_assign,
 // the engine under every ServerKey gate called at /root/reference/base/src/boolean_tree.rs:644-654).
@@ -27,7 +28,15 @@ constexpr int kTrGroup = 16 * kTrRow;
 constexpr int kWaveLdsBytes = 4 * kTrGroup * 16;  // 17408: transpose buffer, aliased by the rotation buffer
 constexpr int kABytes = 1664;                     // modulus-switched mask, u16[<=832]
 constexpr int kWavesPerBlock = 4;
-constexpr int kPbsLdsBytes = kWavesPerBlock * (kWaveLdsBytes + kABytes);
+constexpr int kWavePrivBytes = kWaveLdsBytes + kABytes;
+// Bootstrapping-key ring: the Fourier GGSW of one blind-rotation step (128 KiB) streams through LDS
+// in 8 chunks of 16 KiB (two frequency groups k2 each), filled by LDS-DMA and shared by the 4 waves.
+constexpr int kChunkBytes = 16384;
+constexpr int kChunksPerStep = 8;
+constexpr int kRingSlots = 5;
+constexpr int kRingOffset = kWavesPerBlock * kWavePrivBytes;
+constexpr int kPbsLdsBytes = kRingOffset + kRingSlots * kChunkBytes;  // 158208 of 163840
+constexpr int kConvertLdsBytes = kWavesPerBlock * kWavePrivBytes;
 
 // One bootstrap: u = ca*in[a] + cb*in[b] + (0,..,0,cst), all wrapping u32.
 struct PbsJob {
@@ -204,19 +213,41 @@ __device__ __forceinline__ uint32_t round_torus(double x) {  // nearest integer 
     return __builtin_bit_cast(uint2, x).x;
 }
 
-// bsk_f layout (c64): [i][level][k2][c][row g][t]  ->  the 64 lanes of a wave read 1 KiB contiguous
-__device__ __forceinline__ size_t bsk_index(uint32_t i, int lv, int k2, int c) { return ((((size_t)i * kLevels + lv) * 16 + k2) * kK1 + c) * 64; }
+// bsk_f layout (c64): [i][k2][level][c][row g][t]: one (k2, level, c) row is 1 KiB = the 64 lanes of
+// a wave, and the two k2 groups of a ring chunk are 16 KiB contiguous.
+__device__ __forceinline__ size_t bsk_index(uint32_t i, int lv, int k2, int c) { return ((((size_t)i * 16 + k2) * kLevels + lv) * kK1 + c) * 64; }
+
+// LDS-DMA of chunk `chunk` (global index over all steps) into its ring slot: 16 rows of 1 KiB, 4 per wave.
+__device__ __forceinline__ void ring_issue(const c64 *bsk_f, uint32_t chunk, unsigned char *ring, int wave, int lane) {
+    const c64 *src = bsk_f + (size_t)chunk * (kChunkBytes / 16) + lane;
+    unsigned char *dst = ring + (chunk % kRingSlots) * kChunkBytes;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int row = wave * 4 + j;
+        auto gsrc = (const __attribute__((address_space(1))) void *)(reinterpret_cast<uintptr_t>(src + row * 64));
+        auto ldst = (__attribute__((address_space(3))) void *)(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(dst + row * 1024)));
+        __builtin_amdgcn_global_load_lds(gsrc, ldst, 16, 0, 0);
+    }
+}
 
 // tw: [r][t] c64, e^{i pi t (1 + 4 r)/512}
+//
+// Workgroup = 4 waves = 4 bootstraps that walk the blind rotation in lock step so that they share
+// the bootstrapping key: step i's Fourier GGSW streams through the LDS ring once per workgroup.
+// Chunk schedule (global chunk index ch = 8*i + q): before consuming ch every wave waits for its own
+// DMA rows of ch, then one barrier makes all rows of ch visible and proves every wave is done with
+// ch-1, whose slot is refilled with ch-1+kRingSlots right after the barrier.
 __global__ void __launch_bounds__(256, 1)
     pbs_kernel(const uint32_t *__restrict__ in_base, uint32_t in_stride, const PbsJob *__restrict__ jobs, uint32_t n_jobs,
                const c64 *__restrict__ bsk_f, const c64 *__restrict__ tw, uint32_t n, uint32_t steps, uint32_t *__restrict__ big_out,
                uint32_t big_stride, uint32_t *__restrict__ acc_out) {
     extern __shared__ __align__(16) unsigned char lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, t = lane & 15;
-    const uint32_t job = blockIdx.x * kWavesPerBlock + wave;
-    if (job >= n_jobs) return;  // wave-uniform; the loop has no workgroup barrier
-    unsigned char *wl = lds + wave * (kWaveLdsBytes + kABytes);
+    const uint32_t job_raw = blockIdx.x * kWavesPerBlock + wave;
+    const bool live = job_raw < n_jobs;                 // idle waves of the last workgroup still run the
+    const uint32_t job = live ? job_raw : n_jobs - 1;   // loop (barriers, DMA) on a duplicate job, write nothing
+    unsigned char *wl = lds + wave * kWavePrivBytes;
+    unsigned char *ring = lds + kRingOffset;
     c64 *tr = reinterpret_cast<c64 *>(wl);
     uint32_t *rot = reinterpret_cast<uint32_t *>(wl);
     uint16_t *a_tilde = reinterpret_cast<uint16_t *>(wl + kWaveLdsBytes);
@@ -248,10 +279,15 @@ __global__ void __launch_bounds__(256, 1)
     }
 
     const uint32_t n_steps = steps < n ? steps : n;
+    const uint32_t n_chunks = n_steps * kChunksPerStep;
+    // every ordinary load above has been consumed; from here on the only vector-memory operations in
+    // flight are the ring's LDS-DMA rows, so vmcnt counts them exactly
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (uint32_t ch = 0; ch < kRingSlots - 1 && ch < n_chunks; ch++) ring_issue(bsk_f, ch, ring, wave, lane);
+
     for (uint32_t i = 0; i < n_steps; i++) {
         const int a = __builtin_amdgcn_readfirstlane((int)a_tilde[i]);
-        if (a == 0) continue;  // X^0 - 1 = 0
-        // d = acc * X^a - acc through the rotation buffer, then signed decomposition
+        // d = acc * X^a - acc through the rotation buffer, then signed decomposition (a == 0 gives d = 0)
         wave_lds_fence();
 #pragma unroll
         for (int m = 0; m < 32; m++) rot[g * kRotStride + 16 * m + t] = acc[m];
@@ -259,7 +295,7 @@ __global__ void __launch_bounds__(256, 1)
         uint32_t dig[32];  // level-1 digit in the low half, level-2 digit in the high half
 #pragma unroll
         for (int m = 0; m < 32; m++) {
-            int jj = 16 * m + t - a;  // (-1024, 512)
+            int jj = 16 * m + t - a;  // (-1024, 512]
             uint32_t v = rot[g * kRotStride + (jj & 511)];
             v = ((jj >> 9) & 1) ? 0u - v : v;
             int d1, d2;
@@ -280,18 +316,30 @@ __global__ void __launch_bounds__(256, 1)
         // Fourier-domain multiply-accumulate: row g contributes polynomial g of both levels to all
         // four output polynomials; the sum over rows lands in row c for output polynomial c.
         double our[16], oui[16];
-        const c64 *bi = bsk_f + lane;
 #pragma unroll
-        for (int k2 = 0; k2 < 16; k2++) {
-            double pr[4], pi[4];
+        for (int q = 0; q < kChunksPerStep; q++) {
+            const uint32_t ch = i * kChunksPerStep + q;
+            // own DMA rows of chunk ch have landed: at most the rows of the kRingSlots-2 younger chunks stay in flight
+            if (ch + (kRingSlots - 2) < n_chunks)
+                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (ch + (kRingSlots - 1) < n_chunks) ring_issue(bsk_f, ch + (kRingSlots - 1), ring, wave, lane);
+            const c64 *slot = reinterpret_cast<const c64 *>(ring + (ch % kRingSlots) * kChunkBytes) + lane;
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                c64 b0 = bi[bsk_index(i, 0, k2, c)], b1 = bi[bsk_index(i, 1, k2, c)];
-                pr[c] = f1r[k2] * b0.x - f1i[k2] * b0.y + f2r[k2] * b1.x - f2i[k2] * b1.y;
-                pi[c] = f1r[k2] * b0.y + f1i[k2] * b0.x + f2r[k2] * b1.y + f2i[k2] * b1.x;
+            for (int kk = 0; kk < 2; kk++) {
+                const int k2 = 2 * q + kk;
+                double pr[4], pi[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    c64 b0 = slot[((kk * 2 + 0) * 4 + c) * 64], b1 = slot[((kk * 2 + 1) * 4 + c) * 64];
+                    pr[c] = f1r[k2] * b0.x - f1i[k2] * b0.y + f2r[k2] * b1.x - f2i[k2] * b1.y;
+                    pi[c] = f1r[k2] * b0.y + f1i[k2] * b0.x + f2r[k2] * b1.y + f2i[k2] * b1.x;
+                }
+                our[k2] = reduce_scatter_rows(pr[0], pr[1], pr[2], pr[3]);
+                oui[k2] = reduce_scatter_rows(pi[0], pi[1], pi[2], pi[3]);
             }
-            our[k2] = reduce_scatter_rows(pr[0], pr[1], pr[2], pr[3]);
-            oui[k2] = reduce_scatter_rows(pi[0], pi[1], pi[2], pi[3]);
         }
         fft_inverse(our, oui, twr, twi, tr, g, t);
 #pragma unroll
@@ -301,6 +349,7 @@ __global__ void __launch_bounds__(256, 1)
         }
     }
 
+    if (!live) return;
     if (acc_out) {  // raw accumulator [job][row][N]
 #pragma unroll
         for (int m = 0; m < 32; m++) acc_out[((size_t)job * kK1 + g) * kN + 16 * m + t] = acc[m];
@@ -327,7 +376,7 @@ __global__ void __launch_bounds__(256, 1)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, t = lane & 15;
     const uint32_t row = blockIdx.x * kWavesPerBlock + wave;  // (i * l + lv) * 4 + r
     if (row >= n_rows) return;
-    c64 *tr = reinterpret_cast<c64 *>(lds + wave * (kWaveLdsBytes + kABytes));
+    c64 *tr = reinterpret_cast<c64 *>(lds + wave * kWavePrivBytes);
     double twr[16], twi[16], re[16], im[16];
 #pragma unroll
     for (int r = 0; r < 16; r++) {
@@ -342,10 +391,9 @@ __global__ void __launch_bounds__(256, 1)
         im[q] = (double)(int32_t)src[16 * q + t + 256];
     }
     fft_forward(re, im, twr, twi, tr, g, t);
-    const uint32_t r = row & 3, ilv = row >> 2;  // ilv = i * l + lv
+    const uint32_t r = row & 3, lv = (row >> 2) % kLevels, i = (row >> 2) / kLevels;
 #pragma unroll
-    for (int k2 = 0; k2 < 16; k2++)
-        bsk_f[(((size_t)ilv * 16 + k2) * kK1 + g) * 64 + r * 16 + t] = c64{re[k2] * (1.0 / 256.0), im[k2] * (1.0 / 256.0)};
+    for (int k2 = 0; k2 < 16; k2++) bsk_f[bsk_index(i, lv, k2, g) + r * 16 + t] = c64{re[k2] * (1.0 / 256.0), im[k2] * (1.0 / 256.0)};
 }
 
 }  // namespace tfa
