@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -52,6 +53,8 @@ struct tfa_ctx {
     // stats
     tfa_stats stats{};
     bool profiling = false;
+    uint32_t n_cus = 256;
+    int force_waves = 0;  // 0 = choose per launch; 4 or 8 pins the kernel variant (TFA_PBS_WAVES, for experiments)
     std::vector<EventPair> pending;
 };
 
@@ -177,6 +180,10 @@ extern "C" int tfa_ctx_create(const tfa_params *p, int hip_device, tfa_ctx **out
     ctx->big_stride = (p->glwe_dimension * p->polynomial_size + 1 + 3) / 4 * 4;
     *out = ctx;  // handed out even on failure below so the caller can read the message and destroy it
     HIPCHK(ctx, hipSetDevice(hip_device));
+    hipDeviceProp_t prop;
+    HIPCHK(ctx, hipGetDeviceProperties(&prop, hip_device));
+    if (prop.multiProcessorCount > 0) ctx->n_cus = (uint32_t)prop.multiProcessorCount;
+    if (const char *w = getenv("TFA_PBS_WAVES")) ctx->force_waves = atoi(w) == 8 ? 8 : (atoi(w) == 4 ? 4 : 0);
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     // per-lane twiddles e^{i pi t (1 + 4 r)/512}, [r][t]
     std::vector<c64> tw(256);
@@ -187,7 +194,8 @@ extern "C" int tfa_ctx_create(const tfa_params *p, int hip_device, tfa_ctx **out
         }
     HIPCHK(ctx, hipMalloc(&ctx->d_tw, sizeof(c64) * 256));
     HIPCHK(ctx, hipMemcpy(ctx->d_tw, tw.data(), sizeof(c64) * 256, hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kPbsLdsBytes));
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, PbsGeom<4>::kLdsBytes));
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, PbsGeom<8>::kLdsBytes));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bsk_convert_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kConvertLdsBytes));
     return TFA_OK;
 }
@@ -237,7 +245,7 @@ extern "C" int tfa_keys_upload(tfa_ctx *ctx, const uint32_t *bsk, const uint32_t
     hipError_t e = hipMemcpy(d_std, bsk, bsk_words * sizeof(uint32_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         const uint32_t rows = n * p.pbs_level * (p.glwe_dimension + 1);
-        hipLaunchKernelGGL(bsk_convert_kernel, dim3((rows + kWavesPerBlock - 1) / kWavesPerBlock), dim3(256), kConvertLdsBytes, ctx->stream, d_std,
+        hipLaunchKernelGGL(bsk_convert_kernel, dim3((rows + kConvertWaves - 1) / kConvertWaves), dim3(256), kConvertLdsBytes, ctx->stream, d_std,
                            ctx->d_bsk_f, ctx->d_tw, rows);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -336,8 +344,16 @@ static int launch_pbs(tfa_ctx *ctx, const uint32_t *in_base, uint32_t in_stride,
         HIPCHK(ctx, hipEventCreate(&ep.b));
         HIPCHK(ctx, hipEventRecord(ep.a, ctx->stream));
     }
-    hipLaunchKernelGGL(pbs_kernel, dim3((n_jobs + kWavesPerBlock - 1) / kWavesPerBlock), dim3(256), kPbsLdsBytes, ctx->stream, in_base, in_stride,
-                       d_jobs, n_jobs, ctx->d_bsk_f, ctx->d_tw, ctx->p.lwe_dimension, steps, ctx->d_big, ctx->big_stride, acc_out);
+    // 8 bootstraps per workgroup (two waves per SIMD) give the higher throughput, 4 (one wave per SIMD) the
+    // lower latency per bootstrap: pick whichever finishes this launch sooner on the device's CUs
+    const uint64_t rounds8 = (((uint64_t)n_jobs + 7) / 8 + ctx->n_cus - 1) / ctx->n_cus, rounds4 = (((uint64_t)n_jobs + 3) / 4 + ctx->n_cus - 1) / ctx->n_cus;
+    const bool wide = ctx->force_waves ? ctx->force_waves == 8 : rounds8 * 18 < rounds4 * 10;  // relative time of one round
+    if (wide)
+        hipLaunchKernelGGL(pbs_kernel<8>, dim3((n_jobs + 7) / 8), dim3(512), PbsGeom<8>::kLdsBytes, ctx->stream, in_base, in_stride, d_jobs, n_jobs,
+                           ctx->d_bsk_f, ctx->d_tw, ctx->p.lwe_dimension, steps, ctx->d_big, ctx->big_stride, acc_out);
+    else
+        hipLaunchKernelGGL(pbs_kernel<4>, dim3((n_jobs + 3) / 4), dim3(256), PbsGeom<4>::kLdsBytes, ctx->stream, in_base, in_stride, d_jobs, n_jobs,
+                           ctx->d_bsk_f, ctx->d_tw, ctx->p.lwe_dimension, steps, ctx->d_big, ctx->big_stride, acc_out);
     HIPCHK(ctx, hipGetLastError());
     if (ctx->profiling) {
         HIPCHK(ctx, hipEventRecord(ep.b, ctx->stream));

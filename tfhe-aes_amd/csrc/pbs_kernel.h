@@ -7,7 +7,7 @@
 // size-512 transform is a size-256 complex FFT computed as 16 x 16: a register-resident DFT16 per
 // lane, one 16 x 16 transpose through wave-private LDS, a second register DFT16.  The Fourier
 // domain multiply-accumulate with the bootstrapping key sums over the four rows with the gfx950
-// row/half swap instructions.  The four waves of a workgroup advance in lock step and share the
+// row/half swap instructions.  The waves of a workgroup advance in lock step and share the
 // bootstrapping key through an LDS ring filled by LDS-DMA, one barrier per 16 KiB chunk.
 //
 // What the kernel computes follows tfhe-rs 0.11 (blind_rotate_assign / add_external_product_assign,
@@ -23,20 +23,28 @@ constexpr int kK1 = 4;           // glwe_dimension + 1
 constexpr int kLevels = 2;       // pbs_level
 constexpr int kBaseLog = 10;     // pbs_base_log
 constexpr int kRotStride = 528;  // u32 words per polynomial in the rotation buffer (528 % 32 == 16)
-constexpr int kTrRow = 17;       // complex elements per padded transpose row
+constexpr int kTrRow = 17;       // doubles per padded transpose row
 constexpr int kTrGroup = 16 * kTrRow;
-constexpr int kWaveLdsBytes = 4 * kTrGroup * 16;  // 17408: transpose buffer, aliased by the rotation buffer
-constexpr int kABytes = 1664;                     // modulus-switched mask, u16[<=832]
-constexpr int kWavesPerBlock = 4;
+constexpr int kWaveLdsBytes = 4 * kTrGroup * 8;  // 8704: transpose buffer (one real plane at a time), aliased by the rotation buffer
+constexpr int kABytes = 1664;                    // modulus-switched mask, u16[<=832]
 constexpr int kWavePrivBytes = kWaveLdsBytes + kABytes;
+constexpr int kTwBytes = 4096;                   // per-lane twiddle table shared by all waves
 // Bootstrapping-key ring: the Fourier GGSW of one blind-rotation step (128 KiB) streams through LDS
-// in 8 chunks of 16 KiB (two frequency groups k2 each), filled by LDS-DMA and shared by the 4 waves.
+// in 8 chunks of 16 KiB (two frequency groups k2 each), filled by LDS-DMA and shared by all waves.
 constexpr int kChunkBytes = 16384;
 constexpr int kChunksPerStep = 8;
-constexpr int kRingSlots = 5;
-constexpr int kRingOffset = kWavesPerBlock * kWavePrivBytes;
-constexpr int kPbsLdsBytes = kRingOffset + kRingSlots * kChunkBytes;  // 158208 of 163840
-constexpr int kConvertLdsBytes = kWavesPerBlock * kWavePrivBytes;
+template <int WAVES>
+struct PbsGeom {
+    static constexpr int kSlots = WAVES == 8 ? 4 : 5;
+    static constexpr int kRowsPerWave = 16 / WAVES;  // 1 KiB DMA rows each wave issues per chunk
+    static constexpr int kTwOffset = WAVES * kWavePrivBytes;
+    static constexpr int kRingOffset = kTwOffset + kTwBytes;
+    static constexpr int kLdsBytes = kRingOffset + kSlots * kChunkBytes;
+};
+constexpr int kConvertWaves = 4;
+constexpr int kConvertLdsBytes = kConvertWaves * kWavePrivBytes;
+static_assert(PbsGeom<8>::kLdsBytes <= 163840 && PbsGeom<4>::kLdsBytes <= 163840, "LDS budget");
+static_assert(4 * kRotStride * 4 <= kWaveLdsBytes, "rotation buffer must fit in the transpose buffer");
 
 // One bootstrap: u = ca*in[a] + cb*in[b] + (0,..,0,cst), all wrapping u32.
 struct PbsJob {
@@ -123,42 +131,46 @@ __device__ constexpr double kS32[16] = {0.0, 0.0980171403295606, 0.1950903220161
                                         0.5555702330196022, 0.6343932841636455, 0.7071067811865475, 0.773010453362737, 0.8314696123025452,
                                         0.8819212643483549, 0.9238795325112867, 0.9569403357322089, 0.9807852804032304, 0.9951847266721968};
 
-// 16 x 16 transpose inside each row of 16 lanes through the wave-private LDS buffer:
-// lane t writes element r to [g][r][t] and reads back [g][t][r].
-__device__ __forceinline__ void transpose16(double (&re)[16], double (&im)[16], c64 *tr, int g, int t) {
-    c64 *base = tr + g * kTrGroup;
+// 16 x 16 transpose inside each row of 16 lanes through the wave-private LDS buffer, one real
+// plane at a time: lane t writes element r to [g][r][t] and reads back [g][t][r].
+__device__ __forceinline__ void transpose16_plane(double (&v)[16], double *tr, int g, int t) {
+    double *base = tr + g * kTrGroup;
     wave_lds_fence();  // earlier reads of the aliased buffer are done
 #pragma unroll
-    for (int r = 0; r < 16; r++) base[r * kTrRow + t] = c64{re[r], im[r]};
+    for (int r = 0; r < 16; r++) base[r * kTrRow + t] = v[r];
     wave_lds_fence();
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        c64 v = base[t * kTrRow + r];
-        re[r] = v.x;
-        im[r] = v.y;
-    }
+    for (int r = 0; r < 16; r++) v[r] = base[t * kTrRow + r];
+}
+__device__ __forceinline__ void transpose16(double (&re)[16], double (&im)[16], double *tr, int g, int t) {
+    transpose16_plane(re, tr, g, t);
+    transpose16_plane(im, tr, g, t);
 }
 
 // Forward negacyclic transform of one polynomial per row.  Input: the lane's 32 integer
 // coefficients (re = coefficient 16*n1 + t, im = coefficient 16*n1 + t + 256).  Output: lane k1 = t
 // holds frequency bins k1 + 16*k2, k2 = 0..15.
-__device__ __forceinline__ void fft_forward(double (&re)[16], double (&im)[16], const double (&twr)[16], const double (&twi)[16], c64 *tr, int g,
-                                            int t) {
+__device__ __forceinline__ void fft_forward(double (&re)[16], double (&im)[16], const c64 *twl, double *tr, int g, int t) {
 #pragma unroll
     for (int n1 = 1; n1 < 16; n1++) cmulc<1>(re[n1], im[n1], kC32[n1], kS32[n1]);
     dft16<1>(re, im);
 #pragma unroll
-    for (int k1 = 0; k1 < 16; k1++) cmulc<1>(re[k1], im[k1], twr[k1], twi[k1]);
+    for (int k1 = 0; k1 < 16; k1++) {
+        c64 w = twl[k1 * 16 + t];
+        cmulc<1>(re[k1], im[k1], w.x, w.y);
+    }
     transpose16(re, im, tr, g, t);
     dft16<1>(re, im);
 }
 // Inverse of fft_forward without the 1/256 (folded into the Fourier key).
-__device__ __forceinline__ void fft_inverse(double (&re)[16], double (&im)[16], const double (&twr)[16], const double (&twi)[16], c64 *tr, int g,
-                                            int t) {
+__device__ __forceinline__ void fft_inverse(double (&re)[16], double (&im)[16], const c64 *twl, double *tr, int g, int t) {
     dft16<-1>(re, im);
     transpose16(re, im, tr, g, t);
 #pragma unroll
-    for (int k1 = 0; k1 < 16; k1++) cmulc<-1>(re[k1], im[k1], twr[k1], twi[k1]);
+    for (int k1 = 0; k1 < 16; k1++) {
+        c64 w = twl[k1 * 16 + t];
+        cmulc<-1>(re[k1], im[k1], w.x, w.y);
+    }
     dft16<-1>(re, im);
 #pragma unroll
     for (int n1 = 1; n1 < 16; n1++) cmulc<-1>(re[n1], im[n1], kC32[n1], kS32[n1]);
@@ -213,42 +225,79 @@ __device__ __forceinline__ uint32_t round_torus(double x) {  // nearest integer 
     return __builtin_bit_cast(uint2, x).x;
 }
 
-// bsk_f layout (c64): [i][k2][level][c][row g][t]: one (k2, level, c) row is 1 KiB = the 64 lanes of
-// a wave, and the two k2 groups of a ring chunk are 16 KiB contiguous.
-__device__ __forceinline__ size_t bsk_index(uint32_t i, int lv, int k2, int c) { return ((((size_t)i * 16 + k2) * kLevels + lv) * kK1 + c) * 64; }
+// bsk_f layout (c64): [i][level][k2][c][row g][t]: one (level, k2, c) row is 1 KiB = the 64 lanes of a wave.
+__device__ __forceinline__ size_t bsk_index(uint32_t i, int lv, int k2, int c) { return ((((size_t)i * kLevels + lv) * 16 + k2) * kK1 + c) * 64; }
 
-// LDS-DMA of chunk `chunk` (global index over all steps) into its ring slot: 16 rows of 1 KiB, 4 per wave.
+// Ring chunks.  A chunk is 16 key rows of 1 KiB.  With 4 waves a chunk holds both levels of two
+// frequency groups (the two levels are multiplied and reduced together); with 8 waves it holds one
+// level of four frequency groups (each level is reduced on its own, which halves the live registers).
+template <int WAVES>
+__device__ __forceinline__ size_t chunk_row_index(uint32_t chunk, int row) {
+    const uint32_t i = chunk / kChunksPerStep, q = chunk % kChunksPerStep;
+    if constexpr (WAVES == 8) {
+        return bsk_index(i, q >> 2, 4 * (q & 3) + (row >> 2), row & 3);
+    } else {
+        return bsk_index(i, (row >> 2) & 1, 2 * q + (row >> 3), row & 3);
+    }
+}
+// LDS-DMA of chunk `chunk` (global index over all steps) into its ring slot, 16 / WAVES rows per wave.
+template <int WAVES>
 __device__ __forceinline__ void ring_issue(const c64 *bsk_f, uint32_t chunk, unsigned char *ring, int wave, int lane) {
-    const c64 *src = bsk_f + (size_t)chunk * (kChunkBytes / 16) + lane;
-    unsigned char *dst = ring + (chunk % kRingSlots) * kChunkBytes;
+    using G = PbsGeom<WAVES>;
+    unsigned char *dst = ring + (chunk % G::kSlots) * kChunkBytes;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int row = wave * 4 + j;
-        auto gsrc = (const __attribute__((address_space(1))) void *)(reinterpret_cast<uintptr_t>(src + row * 64));
-        auto ldst = (__attribute__((address_space(3))) void *)(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(dst + row * 1024)));
+    for (int j = 0; j < G::kRowsPerWave; j++) {
+        const int row = wave * G::kRowsPerWave + j;
+        auto gsrc = (const __attribute__((address_space(1))) void *)(reinterpret_cast<uintptr_t>(bsk_f + chunk_row_index<WAVES>(chunk, row) + lane));
+        auto ldst = (__attribute__((address_space(3))) void *)(reinterpret_cast<uintptr_t>(dst + row * 1024));
         __builtin_amdgcn_global_load_lds(gsrc, ldst, 16, 0, 0);
     }
+}
+// Wait for this wave's DMA rows of chunk `ch`, make the chunk visible to the workgroup, refill the slot freed by ch-1.
+template <int WAVES>
+__device__ __forceinline__ const c64 *ring_acquire(const c64 *bsk_f, uint32_t ch, uint32_t n_chunks, unsigned char *ring, int wave, int lane) {
+    using G = PbsGeom<WAVES>;
+    // at most the rows of the kSlots-2 younger chunks stay in flight
+    if (ch + (G::kSlots - 2) < n_chunks) {
+        if constexpr ((G::kSlots - 2) * G::kRowsPerWave == 12)
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if constexpr ((G::kSlots - 2) * G::kRowsPerWave == 4)
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (ch + (G::kSlots - 1) < n_chunks) ring_issue<WAVES>(bsk_f, ch + (G::kSlots - 1), ring, wave, lane);
+    return reinterpret_cast<const c64 *>(ring + (ch % G::kSlots) * kChunkBytes) + lane;
 }
 
 // tw: [r][t] c64, e^{i pi t (1 + 4 r)/512}
 //
-// Workgroup = 4 waves = 4 bootstraps that walk the blind rotation in lock step so that they share
-// the bootstrapping key: step i's Fourier GGSW streams through the LDS ring once per workgroup.
+// Workgroup = WAVES waves = WAVES bootstraps that walk the blind rotation in lock step so that they
+// share the bootstrapping key: step i's Fourier GGSW streams through the LDS ring once per workgroup.
+// WAVES = 8 puts two waves on every SIMD (throughput: one hides the other's LDS and barrier waits);
+// WAVES = 4 keeps one wave per SIMD (lowest latency per bootstrap, used for narrow stages).
 // Chunk schedule (global chunk index ch = 8*i + q): before consuming ch every wave waits for its own
 // DMA rows of ch, then one barrier makes all rows of ch visible and proves every wave is done with
-// ch-1, whose slot is refilled with ch-1+kRingSlots right after the barrier.
-__global__ void __launch_bounds__(256, 1)
+// ch-1, whose slot is refilled with ch-1+kSlots right after the barrier.
+template <int WAVES>
+__global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
     pbs_kernel(const uint32_t *__restrict__ in_base, uint32_t in_stride, const PbsJob *__restrict__ jobs, uint32_t n_jobs,
                const c64 *__restrict__ bsk_f, const c64 *__restrict__ tw, uint32_t n, uint32_t steps, uint32_t *__restrict__ big_out,
                uint32_t big_stride, uint32_t *__restrict__ acc_out) {
+    using G = PbsGeom<WAVES>;
     extern __shared__ __align__(16) unsigned char lds[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, t = lane & 15;
-    const uint32_t job_raw = blockIdx.x * kWavesPerBlock + wave;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keep it (and all ring addressing) scalar
+    const int lane = threadIdx.x & 63, g = lane >> 4, t = lane & 15;
+    const uint32_t job_raw = blockIdx.x * WAVES + wave;
     const bool live = job_raw < n_jobs;                 // idle waves of the last workgroup still run the
     const uint32_t job = live ? job_raw : n_jobs - 1;   // loop (barriers, DMA) on a duplicate job, write nothing
     unsigned char *wl = lds + wave * kWavePrivBytes;
-    unsigned char *ring = lds + kRingOffset;
-    c64 *tr = reinterpret_cast<c64 *>(wl);
+    unsigned char *ring = lds + G::kRingOffset;
+    c64 *twl = reinterpret_cast<c64 *>(lds + G::kTwOffset);
+    double *tr = reinterpret_cast<double *>(wl);
     uint32_t *rot = reinterpret_cast<uint32_t *>(wl);
     uint16_t *a_tilde = reinterpret_cast<uint16_t *>(wl + kWaveLdsBytes);
 
@@ -260,14 +309,8 @@ __global__ void __launch_bounds__(256, 1)
         if (idx == n) u += jb.cst;
         a_tilde[idx] = (uint16_t)modswitch_2n(u);
     }
-    double twr[16], twi[16];
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        c64 v = tw[r * 16 + t];
-        twr[r] = v.x;
-        twi[r] = v.y;
-    }
-    wave_lds_fence();
+    if (threadIdx.x < 256) twl[threadIdx.x] = tw[threadIdx.x];
+    __syncthreads();
     const uint32_t b_tilde = a_tilde[n];
 
     // accumulator = X^{-b~} * (0, 0, 0, 2^29 * (1 + X + ... + X^{N-1}))
@@ -283,7 +326,7 @@ __global__ void __launch_bounds__(256, 1)
     // every ordinary load above has been consumed; from here on the only vector-memory operations in
     // flight are the ring's LDS-DMA rows, so vmcnt counts them exactly
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (uint32_t ch = 0; ch < kRingSlots - 1 && ch < n_chunks; ch++) ring_issue(bsk_f, ch, ring, wave, lane);
+    for (uint32_t ch = 0; ch < G::kSlots - 1 && ch < n_chunks; ch++) ring_issue<WAVES>(bsk_f, ch, ring, wave, lane);
 
     for (uint32_t i = 0; i < n_steps; i++) {
         const int a = __builtin_amdgcn_readfirstlane((int)a_tilde[i]);
@@ -302,46 +345,74 @@ __global__ void __launch_bounds__(256, 1)
             decompose2(v - acc[m], d1, d2);
             dig[m] = ((uint32_t)d1 & 0xFFFFu) | ((uint32_t)d2 << 16);
         }
-        // forward transforms of both digit levels
-        double f1r[16], f1i[16], f2r[16], f2i[16];
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            f1r[q] = (double)((int)(dig[q] << 16) >> 16);
-            f1i[q] = (double)((int)(dig[q + 16] << 16) >> 16);
-            f2r[q] = (double)((int)dig[q] >> 16);
-            f2i[q] = (double)((int)dig[q + 16] >> 16);
-        }
-        fft_forward(f1r, f1i, twr, twi, tr, g, t);
-        fft_forward(f2r, f2i, twr, twi, tr, g, t);
         // Fourier-domain multiply-accumulate: row g contributes polynomial g of both levels to all
         // four output polynomials; the sum over rows lands in row c for output polynomial c.
         double our[16], oui[16];
+        if constexpr (WAVES == 8) {
 #pragma unroll
-        for (int q = 0; q < kChunksPerStep; q++) {
-            const uint32_t ch = i * kChunksPerStep + q;
-            // own DMA rows of chunk ch have landed: at most the rows of the kRingSlots-2 younger chunks stay in flight
-            if (ch + (kRingSlots - 2) < n_chunks)
-                asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (ch + (kRingSlots - 1) < n_chunks) ring_issue(bsk_f, ch + (kRingSlots - 1), ring, wave, lane);
-            const c64 *slot = reinterpret_cast<const c64 *>(ring + (ch % kRingSlots) * kChunkBytes) + lane;
+            for (int q = 0; q < 16; q++) our[q] = oui[q] = 0.0;
+            // a real (not unrolled) loop over the two levels keeps one level's transform live at a time
+#pragma nounroll
+            for (int lv = 0; lv < 2; lv++) {
+                const int sh = lv ? 0 : 16;
+                double fr[16], fi[16];
 #pragma unroll
-            for (int kk = 0; kk < 2; kk++) {
-                const int k2 = 2 * q + kk;
-                double pr[4], pi[4];
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    c64 b0 = slot[((kk * 2 + 0) * 4 + c) * 64], b1 = slot[((kk * 2 + 1) * 4 + c) * 64];
-                    pr[c] = f1r[k2] * b0.x - f1i[k2] * b0.y + f2r[k2] * b1.x - f2i[k2] * b1.y;
-                    pi[c] = f1r[k2] * b0.y + f1i[k2] * b0.x + f2r[k2] * b1.y + f2i[k2] * b1.x;
+                for (int q = 0; q < 16; q++) {
+                    fr[q] = (double)((int)(dig[q] << sh) >> 16);
+                    fi[q] = (double)((int)(dig[q + 16] << sh) >> 16);
                 }
-                our[k2] = reduce_scatter_rows(pr[0], pr[1], pr[2], pr[3]);
-                oui[k2] = reduce_scatter_rows(pi[0], pi[1], pi[2], pi[3]);
+                fft_forward(fr, fi, twl, tr, g, t);
+#pragma unroll
+                for (int qq = 0; qq < 4; qq++) {
+                    const c64 *slot = ring_acquire<WAVES>(bsk_f, i * kChunksPerStep + lv * 4 + qq, n_chunks, ring, wave, lane);
+#pragma unroll
+                    for (int kq = 0; kq < 4; kq++) {
+                        const int k2 = 4 * qq + kq;
+                        double pr[4], pi[4];
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            c64 b = slot[(kq * 4 + c) * 64];
+                            pr[c] = fr[k2] * b.x - fi[k2] * b.y;
+                            pi[c] = fr[k2] * b.y + fi[k2] * b.x;
+                        }
+                        our[k2] += reduce_scatter_rows(pr[0], pr[1], pr[2], pr[3]);
+                        oui[k2] += reduce_scatter_rows(pi[0], pi[1], pi[2], pi[3]);
+                    }
+                }
+            }
+        } else {
+            double f1r[16], f1i[16], f2r[16], f2i[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                f1r[q] = (double)((int)(dig[q] << 16) >> 16);
+                f1i[q] = (double)((int)(dig[q + 16] << 16) >> 16);
+            }
+            fft_forward(f1r, f1i, twl, tr, g, t);
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                f2r[q] = (double)((int)dig[q] >> 16);
+                f2i[q] = (double)((int)dig[q + 16] >> 16);
+            }
+            fft_forward(f2r, f2i, twl, tr, g, t);
+#pragma unroll
+            for (int q = 0; q < kChunksPerStep; q++) {
+                const c64 *slot = ring_acquire<WAVES>(bsk_f, i * kChunksPerStep + q, n_chunks, ring, wave, lane);
+#pragma unroll
+                for (int kk = 0; kk < 2; kk++) {
+                    const int k2 = 2 * q + kk;
+                    double pr[4], pi[4];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        c64 b0 = slot[((kk * 2 + 0) * 4 + c) * 64], b1 = slot[((kk * 2 + 1) * 4 + c) * 64];
+                        pr[c] = f1r[k2] * b0.x - f1i[k2] * b0.y + f2r[k2] * b1.x - f2i[k2] * b1.y;
+                        pi[c] = f1r[k2] * b0.y + f1i[k2] * b0.x + f2r[k2] * b1.y + f2i[k2] * b1.x;
+                    }
+                    our[k2] = reduce_scatter_rows(pr[0], pr[1], pr[2], pr[3]);
+                    oui[k2] = reduce_scatter_rows(pi[0], pi[1], pi[2], pi[3]);
+                }
             }
         }
-        fft_inverse(our, oui, twr, twi, tr, g, t);
+        fft_inverse(our, oui, twl, tr, g, t);
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             acc[q] += round_torus(our[q]);
@@ -374,23 +445,17 @@ __global__ void __launch_bounds__(256, 1)
     bsk_convert_kernel(const uint32_t *__restrict__ bsk, c64 *__restrict__ bsk_f, const c64 *__restrict__ tw, uint32_t n_rows) {
     extern __shared__ __align__(16) unsigned char lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, t = lane & 15;
-    const uint32_t row = blockIdx.x * kWavesPerBlock + wave;  // (i * l + lv) * 4 + r
+    const uint32_t row = blockIdx.x * kConvertWaves + wave;  // (i * l + lv) * 4 + r
     if (row >= n_rows) return;
-    c64 *tr = reinterpret_cast<c64 *>(lds + wave * kWavePrivBytes);
-    double twr[16], twi[16], re[16], im[16];
-#pragma unroll
-    for (int r = 0; r < 16; r++) {
-        c64 v = tw[r * 16 + t];
-        twr[r] = v.x;
-        twi[r] = v.y;
-    }
+    double *tr = reinterpret_cast<double *>(lds + wave * kWavePrivBytes);
+    double re[16], im[16];
     const uint32_t *src = bsk + ((size_t)row * kK1 + g) * kN;
 #pragma unroll
     for (int q = 0; q < 16; q++) {
         re[q] = (double)(int32_t)src[16 * q + t];
         im[q] = (double)(int32_t)src[16 * q + t + 256];
     }
-    fft_forward(re, im, twr, twi, tr, g, t);
+    fft_forward(re, im, tw, tr, g, t);
     const uint32_t r = row & 3, lv = (row >> 2) % kLevels, i = (row >> 2) / kLevels;
 #pragma unroll
     for (int k2 = 0; k2 < 16; k2++) bsk_f[bsk_index(i, lv, k2, g) + r * 16 + t] = c64{re[k2] * (1.0 / 256.0), im[k2] * (1.0 / 256.0)};

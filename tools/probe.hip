@@ -43,6 +43,12 @@ __global__ void __launch_bounds__(256) k_rate(double* out, int iters) {
         x0 *= c; x1 *= c; x2 *= c; x3 *= c; x4 *= c; x5 *= c; x6 *= c; x7 *= c;
         asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
       }
+    } else if (MODE == 5) {  // fma f64 interleaved with int adds
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        x0 = fma(x0, c, d); u0 += u1; x1 = fma(x1, c, d); u1 ^= u2; x2 = fma(x2, c, d); u2 += u3; x3 = fma(x3, c, d); u3 ^= u0;
+        x4 = fma(x4, c, d); u0 += u2; x5 = fma(x5, c, d); u1 ^= u3; x6 = fma(x6, c, d); u2 += u0; x7 = fma(x7, c, d); u3 ^= u1;
+      }
     } else if (MODE == 4) {  // v_mul_lo_u32
 #pragma unroll
       for (int j = 0; j < 16; j++) { u0 = u0 * u1 + 1; u1 = u1 * u2 + 1; u2 = u2 * u3 + 1; u3 = u3 * u0 + 1; }
@@ -79,10 +85,11 @@ int main() {
   std::vector<unsigned> h(256); CK(hipMemcpy(h.data(), d, 1024, hipMemcpyDeviceToHost));
   const char* names[4] = {"p32.vdst", "p32.src0", "p16.vdst", "p16.src0"};
   for (int r = 0; r < 4; r++) { printf("%s:", names[r]); for (int i = 0; i < 64; i++) printf(" %u", h[r * 64 + i]); printf("\n"); }
-  for (int th : {64, 256, 512}) {
-    int blocks = 256 * (th == 64 ? 4 : 1);
+  for (int mult : {1, 2, 4}) {
+    int th = 256, blocks = 256 * mult;   // mult waves per SIMD
+    printf("--- %d wave(s) per SIMD\n", mult);
     rate<0>("fma_f64", 64, blocks, th); rate<1>("add_f64", 64, blocks, th); rate<3>("mul_f64", 64, blocks, th);
-    rate<2>("permlane_swap", 64, blocks, th); rate<4>("mul_lo_u32", 64, blocks, th);
+    rate<2>("permlane_swap", 64, blocks, th); rate<4>("mul_lo_u32", 64, blocks, th); rate<5>("mix_fma_int", 128, blocks, th);
   }
   return 0;
 }
