@@ -95,14 +95,19 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")  # "gloo" rehearses several ranks on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
+    coll_dev = torch.device("cuda", local_rank) if os.environ.get("BENCH_DIST_BACKEND", "nccl") == "nccl" else torch.device("cpu")
     p = E.default_params()
     lwe_sk, glwe_sk, bsk, ksk = E.client_keygen(p, SEED)       # keys replicated: same seed on every rank
     ctx = E.Context(p, local_rank)
@@ -135,7 +140,7 @@ def main():
     st = ctx.stats()
     ctx.set_profiling(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -145,8 +150,8 @@ def main():
     wrong = int((got != np.where(even, 1 - (bits[:G] & bits[G:]), bits[:G] ^ bits[G:])).sum())
     gathered = None
     if world > 1:
-        gathered = shard.gather_blocks(out[None, :128], world, device=torch.device("cuda", local_rank))
-        w = torch.tensor([wrong], dtype=torch.int64, device="cuda")
+        gathered = shard.gather_blocks(out[None, :128], world, device=coll_dev)
+        w = torch.tensor([wrong], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(w)
         wrong = int(w.item())
 
