@@ -562,3 +562,16 @@ extern "C" int tfa_reset_stats(tfa_ctx *ctx) {
     ctx->stats = tfa_stats{};
     return rc;
 }
+
+#ifdef TFA_STAMPS
+// diagnostic builds only: read and clear the per-phase cycle counters of pbs_kernel
+extern "C" int tfa_debug_read_stamps(tfa_ctx *ctx, unsigned long long *out /*[32]*/) {
+    if (!ctx || !out) return TFA_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32));
+    unsigned long long zero[32] = {0};
+    HIPCHK(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zero, sizeof zero));
+    return TFA_OK;
+}
+#endif

@@ -18,6 +18,22 @@
 
 namespace tfa {
 
+// Diagnostic builds (-DTFA_STAMPS) accumulate s_memtime deltas per phase for wave 0 of workgroup 0
+// into g_stamps; the shipped library compiles the stamps away.
+#ifdef TFA_STAMPS
+__device__ unsigned long long g_stamps[32];
+#define TFA_STAMP_DECL unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime(); const bool stamp_on = blockIdx.x == 0 && threadIdx.x == 0;
+#define TFA_STAMP(idx)                                                        \
+    do {                                                                      \
+        unsigned long long now_ = __builtin_amdgcn_s_memtime();               \
+        if (stamp_on) g_stamps[idx] += now_ - stamp_t0;                       \
+        stamp_t0 = now_;                                                      \
+    } while (0)
+#else
+#define TFA_STAMP_DECL
+#define TFA_STAMP(idx)
+#endif
+
 constexpr int kN = 512;          // polynomial size
 constexpr int kK1 = 4;           // glwe_dimension + 1
 constexpr int kLevels = 2;       // pbs_level
@@ -58,9 +74,10 @@ struct c64 {
     double x, y;
 };
 
+// Orders this wave's LDS accesses for the compiler (the LDS executes one wave's instructions in
+// order, so no hardware wait is needed); arithmetic may still be scheduled across it.
 __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
@@ -177,6 +194,9 @@ __device__ __forceinline__ void fft_inverse(double (&re)[16], double (&im)[16], 
 }
 
 // ---- cross-row reduction ---------------------------------------------------------------------
+// (Measured alternative: routing these exchanges through the LDS crossbar with ds_swizzle /
+// ds_bpermute frees the vector pipe but runs 12-40 % slower: the exchanges sit on the dependency
+// chain of every frequency group and at most 15 LDS operations can be in flight per wave.)
 // x[lanes 32..63] <-> y[lanes 0..31]
 __device__ __forceinline__ void swap_halves(double &x, double &y) {
     uint2 a = __builtin_bit_cast(uint2, x), b = __builtin_bit_cast(uint2, y);
@@ -328,7 +348,9 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (uint32_t ch = 0; ch < G::kSlots - 1 && ch < n_chunks; ch++) ring_issue<WAVES>(bsk_f, ch, ring, wave, lane);
 
+    TFA_STAMP_DECL
     for (uint32_t i = 0; i < n_steps; i++) {
+        TFA_STAMP(0);
         const int a = __builtin_amdgcn_readfirstlane((int)a_tilde[i]);
         // d = acc * X^a - acc through the rotation buffer, then signed decomposition (a == 0 gives d = 0)
         wave_lds_fence();
@@ -345,6 +367,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
             decompose2(v - acc[m], d1, d2);
             dig[m] = ((uint32_t)d1 & 0xFFFFu) | ((uint32_t)d2 << 16);
         }
+        TFA_STAMP(1);  // rotate + decompose
         // Fourier-domain multiply-accumulate: row g contributes polynomial g of both levels to all
         // four output polynomials; the sum over rows lands in row c for output polynomial c.
         double our[16], oui[16];
@@ -361,10 +384,13 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
                     fr[q] = (double)((int)(dig[q] << sh) >> 16);
                     fi[q] = (double)((int)(dig[q + 16] << sh) >> 16);
                 }
+                TFA_STAMP(2);
                 fft_forward(fr, fi, twl, tr, g, t);
+                TFA_STAMP(3);  // forward transform
 #pragma unroll
                 for (int qq = 0; qq < 4; qq++) {
                     const c64 *slot = ring_acquire<WAVES>(bsk_f, i * kChunksPerStep + lv * 4 + qq, n_chunks, ring, wave, lane);
+                    TFA_STAMP(4);  // ring wait + barrier + refill issue
 #pragma unroll
                     for (int kq = 0; kq < 4; kq++) {
                         const int k2 = 4 * qq + kq;
@@ -378,6 +404,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
                         our[k2] += reduce_scatter_rows(pr[0], pr[1], pr[2], pr[3]);
                         oui[k2] += reduce_scatter_rows(pi[0], pi[1], pi[2], pi[3]);
                     }
+                    TFA_STAMP(5);  // key products + row reduction of one chunk
                 }
             }
         } else {
@@ -394,9 +421,11 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
                 f2i[q] = (double)((int)dig[q + 16] >> 16);
             }
             fft_forward(f2r, f2i, twl, tr, g, t);
+            TFA_STAMP(3);
 #pragma unroll
             for (int q = 0; q < kChunksPerStep; q++) {
                 const c64 *slot = ring_acquire<WAVES>(bsk_f, i * kChunksPerStep + q, n_chunks, ring, wave, lane);
+                TFA_STAMP(4);
 #pragma unroll
                 for (int kk = 0; kk < 2; kk++) {
                     const int k2 = 2 * q + kk;
@@ -410,14 +439,17 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
                     our[k2] = reduce_scatter_rows(pr[0], pr[1], pr[2], pr[3]);
                     oui[k2] = reduce_scatter_rows(pi[0], pi[1], pi[2], pi[3]);
                 }
+                TFA_STAMP(5);
             }
         }
         fft_inverse(our, oui, twl, tr, g, t);
+        TFA_STAMP(6);  // inverse transform
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             acc[q] += round_torus(our[q]);
             acc[q + 16] += round_torus(oui[q]);
         }
+        TFA_STAMP(7);  // rounding + accumulate
     }
 
     if (!live) return;
