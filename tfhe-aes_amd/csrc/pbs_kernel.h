@@ -53,7 +53,11 @@ template <int WAVES>
 struct PbsGeom {
     static constexpr int kSlots = WAVES == 8 ? 4 : 5;
     static constexpr int kRowsPerWave = 16 / WAVES;  // 1 KiB DMA rows each wave issues per chunk
-    static constexpr int kTwOffset = WAVES * kWavePrivBytes;
+    // one wave per SIMD (WAVES == 4) has no partner wave to hide its LDS round trips, so it gets a second
+    // transpose buffer and overlaps two transposes with each other and with arithmetic
+    static constexpr int kTrBuffers = WAVES == 8 ? 1 : 2;
+    static constexpr int kWaveBytes = kTrBuffers * kWaveLdsBytes + kABytes;
+    static constexpr int kTwOffset = WAVES * kWaveBytes;
     static constexpr int kRingOffset = kTwOffset + kTwBytes;
     static constexpr int kLdsBytes = kRingOffset + kSlots * kChunkBytes;
 };
@@ -193,6 +197,71 @@ __device__ __forceinline__ void fft_inverse(double (&re)[16], double (&im)[16], 
     for (int n1 = 1; n1 < 16; n1++) cmulc<-1>(re[n1], im[n1], kC32[n1], kS32[n1]);
 }
 
+// Two independent forward transforms interleaved (two transpose buffers): the LDS round trips of one
+// overlap the arithmetic of the other.  Used by the one-wave-per-SIMD variant.
+__device__ __forceinline__ void fft_forward2(double (&ar)[16], double (&ai)[16], double (&br)[16], double (&bi)[16], const c64 *twl, double *trA,
+                                             double *trB, int g, int t) {
+#pragma unroll
+    for (int n1 = 1; n1 < 16; n1++) {
+        cmulc<1>(ar[n1], ai[n1], kC32[n1], kS32[n1]);
+        cmulc<1>(br[n1], bi[n1], kC32[n1], kS32[n1]);
+    }
+    dft16<1>(ar, ai);
+    dft16<1>(br, bi);
+#pragma unroll
+    for (int k1 = 0; k1 < 16; k1++) {
+        c64 w = twl[k1 * 16 + t];
+        cmulc<1>(ar[k1], ai[k1], w.x, w.y);
+        cmulc<1>(br[k1], bi[k1], w.x, w.y);
+    }
+    double *pa = trA + g * kTrGroup, *pb = trB + g * kTrGroup;
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 16; r++) pa[r * kTrRow + t] = ar[r];
+#pragma unroll
+    for (int r = 0; r < 16; r++) pb[r * kTrRow + t] = br[r];
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 16; r++) ar[r] = pa[t * kTrRow + r];
+#pragma unroll
+    for (int r = 0; r < 16; r++) br[r] = pb[t * kTrRow + r];
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 16; r++) pa[r * kTrRow + t] = ai[r];
+#pragma unroll
+    for (int r = 0; r < 16; r++) pb[r * kTrRow + t] = bi[r];
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 16; r++) ai[r] = pa[t * kTrRow + r];
+#pragma unroll
+    for (int r = 0; r < 16; r++) bi[r] = pb[t * kTrRow + r];
+    dft16<1>(ar, ai);
+    dft16<1>(br, bi);
+}
+// Inverse transform with the real and imaginary planes in separate buffers (no wait between planes).
+__device__ __forceinline__ void fft_inverse2buf(double (&re)[16], double (&im)[16], const c64 *twl, double *trA, double *trB, int g, int t) {
+    dft16<-1>(re, im);
+    double *pa = trA + g * kTrGroup, *pb = trB + g * kTrGroup;
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 16; r++) pa[r * kTrRow + t] = re[r];
+#pragma unroll
+    for (int r = 0; r < 16; r++) pb[r * kTrRow + t] = im[r];
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 16; r++) re[r] = pa[t * kTrRow + r];
+#pragma unroll
+    for (int r = 0; r < 16; r++) im[r] = pb[t * kTrRow + r];
+#pragma unroll
+    for (int k1 = 0; k1 < 16; k1++) {
+        c64 w = twl[k1 * 16 + t];
+        cmulc<-1>(re[k1], im[k1], w.x, w.y);
+    }
+    dft16<-1>(re, im);
+#pragma unroll
+    for (int n1 = 1; n1 < 16; n1++) cmulc<-1>(re[n1], im[n1], kC32[n1], kS32[n1]);
+}
+
 // ---- cross-row reduction ---------------------------------------------------------------------
 // (Measured alternative: routing these exchanges through the LDS crossbar with ds_swizzle /
 // ds_bpermute frees the vector pipe but runs 12-40 % slower: the exchanges sit on the dependency
@@ -273,10 +342,15 @@ __device__ __forceinline__ void ring_issue(const c64 *bsk_f, uint32_t chunk, uns
         __builtin_amdgcn_global_load_lds(gsrc, ldst, 16, 0, 0);
     }
 }
-// Wait for this wave's DMA rows of chunk `ch`, make the chunk visible to the workgroup, refill the slot freed by ch-1.
+// Chunk hand-over, in three steps so diagnostic builds can time them apart:
+//   ring_wait_own : this wave's DMA rows of chunk `ch` have landed (and, with 4 waves, its LDS reads of the
+//                   chunk whose slot is about to be refilled have returned)
+//   s_barrier     : all rows of `ch` are visible and every wave is done with chunk ch-1
+//   ring_refill   : the slot freed by ch-1 is refilled with chunk ch-1+kSlots
 template <int WAVES>
-__device__ __forceinline__ const c64 *ring_acquire(const c64 *bsk_f, uint32_t ch, uint32_t n_chunks, unsigned char *ring, int wave, int lane) {
+__device__ __forceinline__ void ring_wait_own(uint32_t ch, uint32_t n_chunks) {
     using G = PbsGeom<WAVES>;
+    if constexpr (WAVES == 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // at most the rows of the kSlots-2 younger chunks stay in flight
     if (ch + (G::kSlots - 2) < n_chunks) {
         if constexpr ((G::kSlots - 2) * G::kRowsPerWave == 12)
@@ -288,10 +362,25 @@ __device__ __forceinline__ const c64 *ring_acquire(const c64 *bsk_f, uint32_t ch
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_s_barrier();
+}
+template <int WAVES>
+__device__ __forceinline__ const c64 *ring_refill(const c64 *bsk_f, uint32_t ch, uint32_t n_chunks, unsigned char *ring, int wave, int lane) {
+    using G = PbsGeom<WAVES>;
     if (ch + (G::kSlots - 1) < n_chunks) ring_issue<WAVES>(bsk_f, ch + (G::kSlots - 1), ring, wave, lane);
     return reinterpret_cast<const c64 *>(ring + (ch % G::kSlots) * kChunkBytes) + lane;
 }
+#define TFA_RING_ACQUIRE(slot_var, ch_expr)                                     \
+    const c64 *slot_var;                                                        \
+    {                                                                           \
+        const uint32_t ch_ = (ch_expr);                                         \
+        TFA_STAMP(8);                                                           \
+        ring_wait_own<WAVES>(ch_, n_chunks);                                    \
+        TFA_STAMP(9);                                                           \
+        __builtin_amdgcn_s_barrier();                                           \
+        TFA_STAMP(10);                                                          \
+        slot_var = ring_refill<WAVES>(bsk_f, ch_, n_chunks, ring, wave, lane);  \
+        TFA_STAMP(11);                                                          \
+    }
 
 // tw: [r][t] c64, e^{i pi t (1 + 4 r)/512}
 //
@@ -314,12 +403,13 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
     const uint32_t job_raw = blockIdx.x * WAVES + wave;
     const bool live = job_raw < n_jobs;                 // idle waves of the last workgroup still run the
     const uint32_t job = live ? job_raw : n_jobs - 1;   // loop (barriers, DMA) on a duplicate job, write nothing
-    unsigned char *wl = lds + wave * kWavePrivBytes;
+    unsigned char *wl = lds + wave * G::kWaveBytes;
     unsigned char *ring = lds + G::kRingOffset;
     c64 *twl = reinterpret_cast<c64 *>(lds + G::kTwOffset);
     double *tr = reinterpret_cast<double *>(wl);
+    double *tr2 = reinterpret_cast<double *>(wl + (G::kTrBuffers - 1) * kWaveLdsBytes);  // second transpose buffer (4 waves)
     uint32_t *rot = reinterpret_cast<uint32_t *>(wl);
-    uint16_t *a_tilde = reinterpret_cast<uint16_t *>(wl + kWaveLdsBytes);
+    uint16_t *a_tilde = reinterpret_cast<uint16_t *>(wl + G::kTrBuffers * kWaveLdsBytes);
 
     // gate linear combination + modulus switch
     const PbsJob jb = jobs[job];
@@ -389,7 +479,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
                 TFA_STAMP(3);  // forward transform
 #pragma unroll
                 for (int qq = 0; qq < 4; qq++) {
-                    const c64 *slot = ring_acquire<WAVES>(bsk_f, i * kChunksPerStep + lv * 4 + qq, n_chunks, ring, wave, lane);
+                    TFA_RING_ACQUIRE(slot, i * kChunksPerStep + lv * 4 + qq)
                     TFA_STAMP(4);  // ring wait + barrier + refill issue
 #pragma unroll
                     for (int kq = 0; kq < 4; kq++) {
@@ -413,18 +503,26 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
             for (int q = 0; q < 16; q++) {
                 f1r[q] = (double)((int)(dig[q] << 16) >> 16);
                 f1i[q] = (double)((int)(dig[q + 16] << 16) >> 16);
-            }
-            fft_forward(f1r, f1i, twl, tr, g, t);
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
                 f2r[q] = (double)((int)dig[q] >> 16);
                 f2i[q] = (double)((int)dig[q + 16] >> 16);
             }
-            fft_forward(f2r, f2i, twl, tr, g, t);
+            fft_forward2(f1r, f1i, f2r, f2i, twl, tr, tr2, g, t);
             TFA_STAMP(3);
+            // key words of a chunk are read into registers one barrier ahead of their use, so the LDS read
+            // latency and the barrier hide behind the products of the previous chunk
+            c64 kb[2][16];
+            {
+                TFA_RING_ACQUIRE(slot, i * kChunksPerStep)
+#pragma unroll
+                for (int r = 0; r < 16; r++) kb[0][r] = slot[r * 64];
+            }
 #pragma unroll
             for (int q = 0; q < kChunksPerStep; q++) {
-                const c64 *slot = ring_acquire<WAVES>(bsk_f, i * kChunksPerStep + q, n_chunks, ring, wave, lane);
+                if (q + 1 < kChunksPerStep) {
+                    TFA_RING_ACQUIRE(slot, i * kChunksPerStep + q + 1)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) kb[(q + 1) & 1][r] = slot[r * 64];
+                }
                 TFA_STAMP(4);
 #pragma unroll
                 for (int kk = 0; kk < 2; kk++) {
@@ -432,7 +530,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
                     double pr[4], pi[4];
 #pragma unroll
                     for (int c = 0; c < 4; c++) {
-                        c64 b0 = slot[((kk * 2 + 0) * 4 + c) * 64], b1 = slot[((kk * 2 + 1) * 4 + c) * 64];
+                        const c64 b0 = kb[q & 1][(kk * 2 + 0) * 4 + c], b1 = kb[q & 1][(kk * 2 + 1) * 4 + c];
                         pr[c] = f1r[k2] * b0.x - f1i[k2] * b0.y + f2r[k2] * b1.x - f2i[k2] * b1.y;
                         pi[c] = f1r[k2] * b0.y + f1i[k2] * b0.x + f2r[k2] * b1.y + f2i[k2] * b1.x;
                     }
@@ -442,6 +540,9 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
                 TFA_STAMP(5);
             }
         }
+        if constexpr (WAVES == 4)
+            fft_inverse2buf(our, oui, twl, tr, tr2, g, t);
+        else
         fft_inverse(our, oui, twl, tr, g, t);
         TFA_STAMP(6);  // inverse transform
 #pragma unroll

@@ -21,5 +21,7 @@ st = ctx.stats()
 names = ["loop overhead", "rotate+decompose", "digit convert", "forward FFT", "ring wait+barrier", "key MAC+reduce", "inverse FFT", "round+accumulate"]
 tot = sum(buf[i] for i in range(8))
 print(f"G={G} waves={os.environ.get('TFA_PBS_WAVES','auto')} pbs {st.pbs_kernel_ms:.2f} ms; stamps total {tot} ticks ({tot/805:.0f} per step; s_memtime ticks at 100 MHz)")
+names += ["(acquire) pre", "(acquire) own-DMA/LDS wait", "(acquire) barrier", "(acquire) refill issue"]
+tot = sum(buf[i] for i in range(12))
 for i, n in enumerate(names):
-    print(f"  {n:20s} {buf[i]/805:9.1f} ticks/step  {100.0*buf[i]/tot:5.1f}%")
+    print(f"  {n:28s} {buf[i]/805:9.1f} ticks/step  {100.0*buf[i]/tot:5.1f}%")
