@@ -37,9 +37,10 @@ def test_keyswitch_bit_exact(gpu_ctx, oracle, okeys):
 
 
 def test_keyswitch_tile_sizes_bit_exact(gpu_ctx, oracle, okeys):
-    """Every tile width of the keyswitch kernel (batches of 1, 1100 and 8200 gates)."""
+    """Every tile width of the keyswitch kernel, with and without the split over input coefficients
+    that narrow batches use (partial sums combined with integer atomics)."""
     rng = np.random.default_rng(2)
-    for count in (1, 1100, 8200):
+    for count in (1, 37, 300, 1100, 2500, 8200):
         big = rng.integers(0, 2**32, (count, gpu_ctx.big + 1), dtype=np.uint64).astype(np.uint32)
         got = gpu_ctx.keyswitch_batch(big)
         for i in (0, count // 2, count - 1):

@@ -373,16 +373,26 @@ static int launch_ks(tfa_ctx *ctx, const KsJob *d_jobs, uint32_t n_jobs, uint32_
         HIPCHK(ctx, hipEventRecord(ep.a, ctx->stream));
     }
     const uint32_t big_dim = p.glwe_dimension * p.polynomial_size;
-#define KS_LAUNCH(TG)                                                                                                                         \
-    hipLaunchKernelGGL(keyswitch_kernel<TG>, dim3((n_jobs + TG - 1) / TG), dim3(832), kKsChunk *p.ks_level *TG * sizeof(int32_t), ctx->stream, \
-                       ctx->d_big, ctx->big_stride, d_jobs, n_jobs, ctx->d_ksk, ctx->ksk_stride, p.lwe_dimension, big_dim, p.ks_base_log,     \
-                       p.ks_level, out_base, out_stride)
-    if (n_jobs >= 32 * 256)
-        KS_LAUNCH(32);
-    else if (n_jobs >= 8 * 128)
-        KS_LAUNCH(8);
-    else
-        KS_LAUNCH(2);
+#define KS_LAUNCH(TG, UNROLL, SPLIT)                                                                                                         \
+    hipLaunchKernelGGL((keyswitch_kernel<TG, UNROLL>), dim3((n_jobs + TG - 1) / TG, SPLIT), dim3(832), kKsChunk *p.ks_level *TG * sizeof(int32_t), \
+                       ctx->stream, ctx->d_big, ctx->big_stride, d_jobs, n_jobs, ctx->d_ksk, ctx->ksk_stride, p.lwe_dimension, big_dim,            \
+                       p.ks_base_log, p.ks_level, out_base, out_stride)
+    if (n_jobs >= 32 * 256) {
+        KS_LAUNCH(32, 2, 1);
+    } else if (n_jobs >= 8 * 256) {
+        KS_LAUNCH(8, 8, 1);
+    } else {
+        // narrow stage: small gate tiles, and the input coefficients split over enough workgroups to occupy the CUs
+        const uint32_t tiles = (n_jobs + 1) / 2, chunks = (big_dim + kKsChunk - 1) / kKsChunk;
+        uint32_t split = (ctx->n_cus + tiles - 1) / tiles;
+        if (split > chunks) split = chunks;
+        if (split > 1) {
+            hipLaunchKernelGGL(keyswitch_init_kernel, dim3(n_jobs), dim3(256), 0, ctx->stream, ctx->d_big, ctx->big_stride, d_jobs, n_jobs,
+                               p.lwe_dimension, big_dim, out_base, out_stride);
+            HIPCHK(ctx, hipGetLastError());
+        }
+        KS_LAUNCH(2, 16, split);
+    }
 #undef KS_LAUNCH
     HIPCHK(ctx, hipGetLastError());
     if (ctx->profiling) {

@@ -26,7 +26,11 @@ struct KsJob {
     uint32_t out;
 };
 
-template <int TG>
+// TG gates per workgroup; UNROLL key rows in flight per lane.  gridDim.y > 1 splits the kN input
+// coefficients over workgroups (narrow stages: more CUs share the key stream); the partial sums are
+// then combined with integer atomics, which keeps the result bit-exact whatever the order.  In that
+// mode the output rows must have been initialised by keyswitch_init_kernel.
+template <int TG, int UNROLL>
 __global__ void __launch_bounds__(832)
     keyswitch_kernel(const uint32_t *__restrict__ big, uint32_t big_stride, const KsJob *__restrict__ jobs, uint32_t n_jobs,
                      const uint32_t *__restrict__ ksk, uint32_t ksk_stride, uint32_t n, uint32_t big_dim, uint32_t base_log, uint32_t levels,
@@ -36,12 +40,16 @@ __global__ void __launch_bounds__(832)
     const uint32_t col = wave * kKsLanesUsed + lane;
     const bool col_ok = lane < kKsLanesUsed && col <= n;
     const uint32_t g0 = blockIdx.x * TG;
+    const bool split = gridDim.y > 1;
+    const uint32_t chunks = (big_dim + kKsChunk - 1) / kKsChunk;
+    const uint32_t c_begin = (uint32_t)((uint64_t)chunks * blockIdx.y / gridDim.y), c_end = (uint32_t)((uint64_t)chunks * (blockIdx.y + 1) / gridDim.y);
     uint32_t acc[TG];
 #pragma unroll
     for (int g = 0; g < TG; g++) acc[g] = 0;
 
     const uint32_t rep = base_log * levels, non_rep = 32 - rep, mask = (1u << base_log) - 1u;
-    for (uint32_t i0 = 0; i0 < big_dim; i0 += kKsChunk) {
+    for (uint32_t cidx = c_begin; cidx < c_end; cidx++) {
+        const uint32_t i0 = cidx * kKsChunk;
         __syncthreads();
         // decompose big[gate][i0 .. i0+chunk) for the TG gates of the tile
         for (uint32_t p = threadIdx.x; p < TG * kKsChunk; p += blockDim.x) {
@@ -64,10 +72,21 @@ __global__ void __launch_bounds__(832)
         }
         __syncthreads();
         if (col_ok) {
-            const uint32_t rows = kKsChunk * levels;
+            const uint32_t rows = (i0 + kKsChunk <= big_dim ? kKsChunk : big_dim - i0) * levels;
             const uint32_t *kp = ksk + (size_t)i0 * levels * ksk_stride + col;
-#pragma unroll 2
-            for (uint32_t r = 0; r < rows; r++) {
+            uint32_t r = 0;
+            for (; r + UNROLL <= rows; r += UNROLL) {
+                uint32_t x[UNROLL];
+#pragma unroll
+                for (int u = 0; u < UNROLL; u++) x[u] = kp[(size_t)(r + u) * ksk_stride];
+#pragma unroll
+                for (int u = 0; u < UNROLL; u++) {
+                    const int32_t *d = digs + (r + u) * TG;
+#pragma unroll
+                    for (int g = 0; g < TG; g++) acc[g] -= (uint32_t)d[g] * x[u];
+                }
+            }
+            for (; r < rows; r++) {
                 uint32_t x = kp[(size_t)r * ksk_stride];
                 const int32_t *d = digs + r * TG;
 #pragma unroll
@@ -81,14 +100,35 @@ __global__ void __launch_bounds__(832)
             uint32_t gi = g0 + g;
             if (gi < n_jobs) {
                 KsJob jb = jobs[gi];
-                uint32_t v = acc[g];
-                if (col == n) {
-                    v += big[(size_t)jb.a * big_stride + big_dim] + jb.cst;
-                    if (jb.b != kNoSlot) v += big[(size_t)jb.b * big_stride + big_dim];
+                uint32_t *dst = out_base + (size_t)jb.out * out_stride + col;
+                if (split) {
+                    atomicAdd(dst, acc[g]);
+                } else {
+                    uint32_t v = acc[g];
+                    if (col == n) {
+                        v += big[(size_t)jb.a * big_stride + big_dim] + jb.cst;
+                        if (jb.b != kNoSlot) v += big[(size_t)jb.b * big_stride + big_dim];
+                    }
+                    *dst = v;
                 }
-                out_base[(size_t)jb.out * out_stride + col] = v;
             }
         }
+    }
+}
+
+// Output rows for the split mode: (0, ..., 0, body)
+__global__ void keyswitch_init_kernel(const uint32_t *__restrict__ big, uint32_t big_stride, const KsJob *__restrict__ jobs, uint32_t n_jobs, uint32_t n,
+                                      uint32_t big_dim, uint32_t *__restrict__ out_base, uint32_t out_stride) {
+    const uint32_t gi = blockIdx.x;
+    if (gi >= n_jobs) return;
+    const KsJob jb = jobs[gi];
+    for (uint32_t col = threadIdx.x; col <= n; col += blockDim.x) {
+        uint32_t v = 0;
+        if (col == n) {
+            v = big[(size_t)jb.a * big_stride + big_dim] + jb.cst;
+            if (jb.b != kNoSlot) v += big[(size_t)jb.b * big_stride + big_dim];
+        }
+        out_base[(size_t)jb.out * out_stride + col] = v;
     }
 }
 
