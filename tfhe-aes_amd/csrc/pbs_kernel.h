@@ -308,9 +308,12 @@ __device__ __forceinline__ void decompose2(uint32_t x, int &d1, int &d2) {
     carry = (((res - 1u) | state) & res) >> 9;
     d1 = (int)res - (int)(carry << 10);
 }
-__device__ __forceinline__ uint32_t round_torus(double x) {  // nearest integer mod 2^32, |x| < 2^62
-    x -= 4294967296.0 * __builtin_rint(x * (1.0 / 4294967296.0));
-    x += 6755399441055744.0;  // 1.5 * 2^52: low mantissa word = two's complement integer
+// Nearest integer mod 2^32 of an inverse-transform output.  |x| < 2^51 always holds here: x is a sum of
+// 4096 products of a digit (|d| <= 2^9) and a key word (|w| < 2^31), whose standard deviation is about
+// 2^44.  Adding 1.5 * 2^52 then leaves round-to-nearest-even(x) as a two's complement integer in the
+// mantissa, and the low word is the torus value.
+__device__ __forceinline__ uint32_t round_torus(double x) {
+    x += 6755399441055744.0;
     return __builtin_bit_cast(uint2, x).x;
 }
 
@@ -333,6 +336,9 @@ __device__ __forceinline__ size_t chunk_row_index(uint32_t chunk, int row) {
 template <int WAVES>
 __device__ __forceinline__ void ring_issue(const c64 *bsk_f, uint32_t chunk, unsigned char *ring, int wave, int lane) {
     using G = PbsGeom<WAVES>;
+#ifdef TFA_EXP_NODMA  // timing experiment: no key traffic at all (results are garbage)
+    return;
+#endif
     unsigned char *dst = ring + (chunk % G::kSlots) * kChunkBytes;
 #pragma unroll
     for (int j = 0; j < G::kRowsPerWave; j++) {
@@ -369,6 +375,11 @@ __device__ __forceinline__ const c64 *ring_refill(const c64 *bsk_f, uint32_t ch,
     if (ch + (G::kSlots - 1) < n_chunks) ring_issue<WAVES>(bsk_f, ch + (G::kSlots - 1), ring, wave, lane);
     return reinterpret_cast<const c64 *>(ring + (ch % G::kSlots) * kChunkBytes) + lane;
 }
+#ifdef TFA_EXP_NOBARRIER  // timing experiment: waves run free (results are garbage)
+#define TFA_RING_BARRIER() ((void)0)
+#else
+#define TFA_RING_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
 #define TFA_RING_ACQUIRE(slot_var, ch_expr)                                     \
     const c64 *slot_var;                                                        \
     {                                                                           \
@@ -376,7 +387,7 @@ __device__ __forceinline__ const c64 *ring_refill(const c64 *bsk_f, uint32_t ch,
         TFA_STAMP(8);                                                           \
         ring_wait_own<WAVES>(ch_, n_chunks);                                    \
         TFA_STAMP(9);                                                           \
-        __builtin_amdgcn_s_barrier();                                           \
+        TFA_RING_BARRIER();                                                     \
         TFA_STAMP(10);                                                          \
         slot_var = ring_refill<WAVES>(bsk_f, ch_, n_chunks, ring, wave, lane);  \
         TFA_STAMP(11);                                                          \
@@ -447,7 +458,8 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
 #pragma unroll
         for (int m = 0; m < 32; m++) rot[g * kRotStride + 16 * m + t] = acc[m];
         wave_lds_fence();
-        uint32_t dig[32];  // level-1 digit in the low half, level-2 digit in the high half
+        uint32_t dig[32];   // 8 waves: level-1 digit in the low half, level-2 digit in the high half
+        double f1r[16], f1i[16], f2r[16], f2i[16];  // 4 waves: both levels' digits, already as doubles
 #pragma unroll
         for (int m = 0; m < 32; m++) {
             int jj = 16 * m + t - a;  // (-1024, 512]
@@ -455,7 +467,15 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
             v = ((jj >> 9) & 1) ? 0u - v : v;
             int d1, d2;
             decompose2(v - acc[m], d1, d2);
-            dig[m] = ((uint32_t)d1 & 0xFFFFu) | ((uint32_t)d2 << 16);
+            if constexpr (WAVES == 8) {
+                dig[m] = ((uint32_t)d1 & 0xFFFFu) | ((uint32_t)d2 << 16);
+            } else if (m < 16) {
+                f1r[m] = (double)d1;
+                f2r[m] = (double)d2;
+            } else {
+                f1i[m - 16] = (double)d1;
+                f2i[m - 16] = (double)d2;
+            }
         }
         TFA_STAMP(1);  // rotate + decompose
         // Fourier-domain multiply-accumulate: row g contributes polynomial g of both levels to all
@@ -498,14 +518,6 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
                 }
             }
         } else {
-            double f1r[16], f1i[16], f2r[16], f2i[16];
-#pragma unroll
-            for (int q = 0; q < 16; q++) {
-                f1r[q] = (double)((int)(dig[q] << 16) >> 16);
-                f1i[q] = (double)((int)(dig[q + 16] << 16) >> 16);
-                f2r[q] = (double)((int)dig[q] >> 16);
-                f2i[q] = (double)((int)dig[q + 16] >> 16);
-            }
             fft_forward2(f1r, f1i, f2r, f2i, twl, tr, tr2, g, t);
             TFA_STAMP(3);
             // key words of a chunk are read into registers one barrier ahead of their use, so the LDS read

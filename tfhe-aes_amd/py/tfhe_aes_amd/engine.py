@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-LIB_PATH = os.path.join(_PKG, "libtfhe_aes_hip.so")
+LIB_PATH = os.environ.get("TFHE_AES_HIP_LIB") or os.path.join(_PKG, "libtfhe_aes_hip.so")
 
 AND, NAND, OR, NOR, XOR, XNOR, MUX, NOT, COPY = range(9)
 
