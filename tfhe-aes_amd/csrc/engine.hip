@@ -12,6 +12,7 @@
 #include "../../include/tfhe_aes_hip.h"
 #include "ks_kernel.h"
 #include "pbs_kernel.h"
+#include "pbs_lat_kernel.h"
 
 using namespace tfa;
 
@@ -34,6 +35,8 @@ struct tfa_ctx {
     c64 *d_bsk_f = nullptr;
     uint32_t *d_ksk = nullptr;
     c64 *d_tw = nullptr;
+    c64 *d_bsk_lat = nullptr;  // second copy of the Fourier key in the latency kernel's layout
+    c64 *d_tw_lat = nullptr;
     uint32_t ksk_stride = 0;
     bool have_keys = false;
     // pool
@@ -54,7 +57,7 @@ struct tfa_ctx {
     tfa_stats stats{};
     bool profiling = false;
     uint32_t n_cus = 256;
-    int force_waves = 0;  // 0 = choose per launch; 4 or 8 pins the kernel variant (TFA_PBS_WAVES, for experiments)
+    int force_waves = 0;  // 0 = choose per launch; 1 (latency kernel), 4 or 8 pins the kernel variant (TFA_PBS_WAVES, for experiments)
     std::vector<EventPair> pending;
 };
 
@@ -183,7 +186,7 @@ extern "C" int tfa_ctx_create(const tfa_params *p, int hip_device, tfa_ctx **out
     hipDeviceProp_t prop;
     HIPCHK(ctx, hipGetDeviceProperties(&prop, hip_device));
     if (prop.multiProcessorCount > 0) ctx->n_cus = (uint32_t)prop.multiProcessorCount;
-    if (const char *w = getenv("TFA_PBS_WAVES")) ctx->force_waves = atoi(w) == 8 ? 8 : (atoi(w) == 4 ? 4 : 0);
+    if (const char *w = getenv("TFA_PBS_WAVES")) ctx->force_waves = atoi(w) == 8 ? 8 : (atoi(w) == 4 ? 4 : (atoi(w) == 1 ? 1 : 0));
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     // per-lane twiddles e^{i pi t (1 + 4 r)/512}, [r][t]
     std::vector<c64> tw(256);
@@ -194,6 +197,17 @@ extern "C" int tfa_ctx_create(const tfa_params *p, int hip_device, tfa_ctx **out
         }
     HIPCHK(ctx, hipMalloc(&ctx->d_tw, sizeof(c64) * 256));
     HIPCHK(ctx, hipMemcpy(ctx->d_tw, tw.data(), sizeof(c64) * 256, hipMemcpyHostToDevice));
+    // latency kernel: twist e^{i pi n/512} then e^{2 pi i k/256}
+    std::vector<c64> twl(512);
+    for (int k = 0; k < 256; k++) {
+        const long double pi = 3.14159265358979323846264338327950288L;
+        twl[k] = c64{(double)cosl(pi * k / 512.0L), (double)sinl(pi * k / 512.0L)};
+        twl[256 + k] = c64{(double)cosl(2.0L * pi * k / 256.0L), (double)sinl(2.0L * pi * k / 256.0L)};
+    }
+    HIPCHK(ctx, hipMalloc(&ctx->d_tw_lat, sizeof(c64) * 512));
+    HIPCHK(ctx, hipMemcpy(ctx->d_tw_lat, twl.data(), sizeof(c64) * 512, hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_lat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLatLdsBytes));
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bsk_convert_lat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLatConvertLdsBytes));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, PbsGeom<4>::kLdsBytes));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, PbsGeom<8>::kLdsBytes));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bsk_convert_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kConvertLdsBytes));
@@ -211,6 +225,8 @@ extern "C" int tfa_ctx_destroy(tfa_ctx *ctx) {
     hipFree(ctx->d_bsk_f);
     hipFree(ctx->d_ksk);
     hipFree(ctx->d_tw);
+    hipFree(ctx->d_bsk_lat);
+    hipFree(ctx->d_tw_lat);
     hipFree(ctx->d_pool);
     hipFree(ctx->d_big);
     hipFree(ctx->d_jobs);
@@ -234,6 +250,7 @@ extern "C" int tfa_keys_upload(tfa_ctx *ctx, const uint32_t *bsk, const uint32_t
     const uint32_t n = p.lwe_dimension, kN_ = p.glwe_dimension * p.polynomial_size;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (!ctx->d_bsk_f) HIPCHK(ctx, hipMalloc(&ctx->d_bsk_f, bsk_words / 2 * sizeof(c64)));  // N/2 complex per polynomial
+    if (!ctx->d_bsk_lat) HIPCHK(ctx, hipMalloc(&ctx->d_bsk_lat, bsk_words / 2 * sizeof(c64)));
     if (!ctx->d_ksk) HIPCHK(ctx, hipMalloc(&ctx->d_ksk, (size_t)kN_ * p.ks_level * ctx->ksk_stride * sizeof(uint32_t)));
     // KSK rows padded to the pool stride
     HIPCHK(ctx, hipMemset(ctx->d_ksk, 0, (size_t)kN_ * p.ks_level * ctx->ksk_stride * sizeof(uint32_t)));
@@ -248,6 +265,10 @@ extern "C" int tfa_keys_upload(tfa_ctx *ctx, const uint32_t *bsk, const uint32_t
         hipLaunchKernelGGL(bsk_convert_kernel, dim3((rows + kConvertWaves - 1) / kConvertWaves), dim3(256), kConvertLdsBytes, ctx->stream, d_std,
                            ctx->d_bsk_f, ctx->d_tw, rows);
         e = hipGetLastError();
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(bsk_convert_lat_kernel, dim3(rows), dim3(256), kLatConvertLdsBytes, ctx->stream, d_std, ctx->d_bsk_lat, ctx->d_tw_lat, rows);
+            e = hipGetLastError();
+        }
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     }
     hipFree(d_std);
@@ -344,16 +365,25 @@ static int launch_pbs(tfa_ctx *ctx, const uint32_t *in_base, uint32_t in_stride,
         HIPCHK(ctx, hipEventCreate(&ep.b));
         HIPCHK(ctx, hipEventRecord(ep.a, ctx->stream));
     }
-    // 8 bootstraps per workgroup (two waves per SIMD) give the higher throughput, 4 (one wave per SIMD) the
-    // lower latency per bootstrap: pick whichever finishes this launch sooner on the device's CUs
-    const uint64_t rounds8 = (((uint64_t)n_jobs + 7) / 8 + ctx->n_cus - 1) / ctx->n_cus, rounds4 = (((uint64_t)n_jobs + 3) / 4 + ctx->n_cus - 1) / ctx->n_cus;
-    const bool wide = ctx->force_waves ? ctx->force_waves == 8 : rounds8 * 18 < rounds4 * 10;  // relative time of one round
-    if (wide)
+    // Three mappings, picked by which finishes this launch soonest on the device's CUs: 8 bootstraps per
+    // workgroup (two waves per SIMD, highest throughput), 4 per workgroup (one wave per SIMD), or one
+    // bootstrap spread over the 4 waves of a workgroup (lowest latency, one workgroup per CU).
+    // Relative time of one round of workgroups over the CUs: 18 : 10 : kLatRound.
+    constexpr uint64_t kLatRound = 3;
+    const uint64_t cus = ctx->n_cus;
+    const uint64_t t8 = ((((uint64_t)n_jobs + 7) / 8 + cus - 1) / cus) * 18, t4 = ((((uint64_t)n_jobs + 3) / 4 + cus - 1) / cus) * 10,
+                   t1 = (((uint64_t)n_jobs + cus - 1) / cus) * kLatRound;
+    int variant = t1 <= t4 && t1 <= t8 ? 1 : (t8 < t4 ? 8 : 4);
+    if (ctx->force_waves) variant = ctx->force_waves;
+    if (variant == 8)
         hipLaunchKernelGGL(pbs_kernel<8>, dim3((n_jobs + 7) / 8), dim3(512), PbsGeom<8>::kLdsBytes, ctx->stream, in_base, in_stride, d_jobs, n_jobs,
                            ctx->d_bsk_f, ctx->d_tw, ctx->p.lwe_dimension, steps, ctx->d_big, ctx->big_stride, acc_out);
-    else
+    else if (variant == 4)
         hipLaunchKernelGGL(pbs_kernel<4>, dim3((n_jobs + 3) / 4), dim3(256), PbsGeom<4>::kLdsBytes, ctx->stream, in_base, in_stride, d_jobs, n_jobs,
                            ctx->d_bsk_f, ctx->d_tw, ctx->p.lwe_dimension, steps, ctx->d_big, ctx->big_stride, acc_out);
+    else
+        hipLaunchKernelGGL(pbs_lat_kernel, dim3(n_jobs), dim3(256), kLatLdsBytes, ctx->stream, in_base, in_stride, d_jobs, n_jobs, ctx->d_bsk_lat,
+                           ctx->d_tw_lat, ctx->p.lwe_dimension, steps, ctx->d_big, ctx->big_stride, acc_out);
     HIPCHK(ctx, hipGetLastError());
     if (ctx->profiling) {
         HIPCHK(ctx, hipEventRecord(ep.b, ctx->stream));
