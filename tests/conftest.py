@@ -41,6 +41,26 @@ def gpu_ctx(okeys):
     ctx.close()
 
 
+@pytest.fixture(scope="module", params=[1, 2, 4, 8], ids=lambda v: f"variant{v}")
+def variant_ctx(request, okeys):
+    """Engine context pinned to one bootstrap kernel variant (TFA_PBS_WAVES is read when the context is
+    created): 1 / 2 = one bootstrap per workgroup with one / two workgroups per CU, 4 / 8 = one bootstrap per
+    wave with 4 / 8 waves per workgroup."""
+    from tfhe_aes_amd import engine as E
+    old = os.environ.get("TFA_PBS_WAVES")
+    os.environ["TFA_PBS_WAVES"] = str(request.param)
+    try:
+        ctx = E.Context(E.default_params(), 0)
+    finally:
+        if old is None:
+            del os.environ["TFA_PBS_WAVES"]
+        else:
+            os.environ["TFA_PBS_WAVES"] = old
+    ctx.keys_upload(okeys[2], okeys[3])
+    yield ctx
+    ctx.close()
+
+
 @pytest.fixture(scope="session")
 def hkeys():
     """gen_keys() of the host mirror (its own client-side key generation) on cuda:0."""

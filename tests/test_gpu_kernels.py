@@ -94,6 +94,37 @@ def test_bootstrap_batch_against_fft_oracle(gpu_ctx, oracle, okeys, obsk_f):
     assert identical >= 46
 
 
+def test_every_kernel_variant_bit_exact(variant_ctx, oracle, okeys):
+    """Each mapping of the bootstrap onto the GPU (chosen per launch from the stage width in production)
+    against the exact-integer oracle: accumulator after a few external products, whole bootstraps on a
+    batch that leaves the last workgroup partly idle, and agreement between gates run through the pool."""
+    lwe_sk, glwe_sk, bsk, ksk = okeys
+    bits = np.random.default_rng(21).integers(0, 2, 13).astype(np.uint8)
+    cts = oracle.encrypt_bits(lwe_sk, 90, 0, bits)
+    cts[4, 7] = 0
+    for steps in (0, 1, 3):
+        got = variant_ctx.blind_rotate_batch(cts, steps)
+        for g in (0, 4, 12):
+            assert (got[g] == oracle.blind_rotate(bsk, None, cts[g], steps)).all(), (steps, g)
+    got = variant_ctx.bootstrap_batch(cts)
+    for g in (0, 5, 12):
+        assert (got[g] == oracle.pbs(bsk, None, cts[g])).all()
+    for g in range(13):
+        assert (oracle.phase(glwe_sk, got[g]) < 2**31) == bool(bits[g])
+    # 600 gates through the pool: wider than one workgroup per CU for the latency variants
+    G = 600
+    rng = np.random.default_rng(22)
+    a, b, c = (rng.integers(0, 2, G).astype(np.uint8) for _ in range(3))
+    variant_ctx.pool_reserve(4 * G)
+    for k, x in enumerate((a, b, c)):
+        variant_ctx.pool_write(np.arange(k * G, (k + 1) * G), oracle.encrypt_bits(lwe_sk, 91, k, x))
+    ops = rng.integers(0, 7, G)
+    variant_ctx.stage_submit(E.make_gates(ops, np.arange(G), np.arange(G, 2 * G), np.arange(2 * G, 3 * G), np.arange(3 * G, 4 * G)))
+    variant_ctx.sync()
+    out = variant_ctx.pool_read(np.arange(3 * G, 4 * G))
+    assert (oracle.decrypt_bits(lwe_sk, out) == clear_gate(ops, a, b, c)).all()
+
+
 def clear_gate(op, a, b, c):
     return np.select([op == 0, op == 1, op == 2, op == 3, op == 4, op == 5, op == 6],
                      [a & b, 1 - (a & b), a | b, 1 - (a | b), a ^ b, 1 - (a ^ b), np.where(a == 1, b, c)]).astype(np.uint8)

@@ -57,7 +57,8 @@ struct tfa_ctx {
     tfa_stats stats{};
     bool profiling = false;
     uint32_t n_cus = 256;
-    int force_waves = 0;  // 0 = choose per launch; 1 (latency kernel), 4 or 8 pins the kernel variant (TFA_PBS_WAVES, for experiments)
+    bool trace = false;   // TFA_TRACE=1: one stderr line per submitted stage
+    int force_waves = 0;  // 0 = choose per launch; 1 / 2 (latency kernel, workgroups per CU), 4 or 8 pins the kernel variant (TFA_PBS_WAVES, for experiments)
     std::vector<EventPair> pending;
 };
 
@@ -186,7 +187,8 @@ extern "C" int tfa_ctx_create(const tfa_params *p, int hip_device, tfa_ctx **out
     hipDeviceProp_t prop;
     HIPCHK(ctx, hipGetDeviceProperties(&prop, hip_device));
     if (prop.multiProcessorCount > 0) ctx->n_cus = (uint32_t)prop.multiProcessorCount;
-    if (const char *w = getenv("TFA_PBS_WAVES")) ctx->force_waves = atoi(w) == 8 ? 8 : (atoi(w) == 4 ? 4 : (atoi(w) == 1 ? 1 : 0));
+    if (const char *t = getenv("TFA_TRACE")) ctx->trace = atoi(t) != 0;
+    if (const char *w = getenv("TFA_PBS_WAVES")) ctx->force_waves = (atoi(w) == 8 || atoi(w) == 4 || atoi(w) == 2 || atoi(w) == 1) ? atoi(w) : 0;
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     // per-lane twiddles e^{i pi t (1 + 4 r)/512}, [r][t]
     std::vector<c64> tw(256);
@@ -206,7 +208,8 @@ extern "C" int tfa_ctx_create(const tfa_params *p, int hip_device, tfa_ctx **out
     }
     HIPCHK(ctx, hipMalloc(&ctx->d_tw_lat, sizeof(c64) * 512));
     HIPCHK(ctx, hipMemcpy(ctx->d_tw_lat, twl.data(), sizeof(c64) * 512, hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_lat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLatLdsBytes));
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_lat_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LatGeom<1>::kLdsBytes));
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_lat_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LatGeom<2>::kLdsBytes));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bsk_convert_lat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLatConvertLdsBytes));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, PbsGeom<4>::kLdsBytes));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, PbsGeom<8>::kLdsBytes));
@@ -365,15 +368,16 @@ static int launch_pbs(tfa_ctx *ctx, const uint32_t *in_base, uint32_t in_stride,
         HIPCHK(ctx, hipEventCreate(&ep.b));
         HIPCHK(ctx, hipEventRecord(ep.a, ctx->stream));
     }
-    // Three mappings, picked by which finishes this launch soonest on the device's CUs: 8 bootstraps per
-    // workgroup (two waves per SIMD, highest throughput), 4 per workgroup (one wave per SIMD), or one
-    // bootstrap spread over the 4 waves of a workgroup (lowest latency, one workgroup per CU).
-    // Relative time of one round of workgroups over the CUs: 18 : 10 : kLatRound.
-    constexpr uint64_t kLatRound = 3;
-    const uint64_t cus = ctx->n_cus;
-    const uint64_t t8 = ((((uint64_t)n_jobs + 7) / 8 + cus - 1) / cus) * 18, t4 = ((((uint64_t)n_jobs + 3) / 4 + cus - 1) / cus) * 10,
-                   t1 = (((uint64_t)n_jobs + cus - 1) / cus) * kLatRound;
-    int variant = t1 <= t4 && t1 <= t8 ? 1 : (t8 < t4 ? 8 : 4);
+    // Four mappings, picked by which finishes this launch soonest on the device's CUs (measured time of one
+    // round of workgroups over all CUs, microseconds, MI355X):
+    //   8 bootstraps per workgroup, two waves per SIMD (highest throughput)          16700 per 8 * CUs
+    //   4 bootstraps per workgroup, one wave per SIMD                                 9300 per 4 * CUs
+    //   one bootstrap spread over the 4 waves of a workgroup, one workgroup per CU    3700 per CUs
+    //   the same with two workgroups per CU                                           5900 per 2 * CUs
+    const uint64_t cus = ctx->n_cus, P = n_jobs;
+    const uint64_t t8 = ((P + 8 * cus - 1) / (8 * cus)) * 16700, t4 = ((P + 4 * cus - 1) / (4 * cus)) * 9300;
+    const uint64_t lat_rest = P % (2 * cus), t_lat = (P / (2 * cus)) * 5900 + (lat_rest == 0 ? 0 : lat_rest <= cus ? 3700 : 5900);
+    int variant = t_lat <= t4 && t_lat <= t8 ? (P > cus ? 2 : 1) : (t8 < t4 ? 8 : 4);
     if (ctx->force_waves) variant = ctx->force_waves;
     if (variant == 8)
         hipLaunchKernelGGL(pbs_kernel<8>, dim3((n_jobs + 7) / 8), dim3(512), PbsGeom<8>::kLdsBytes, ctx->stream, in_base, in_stride, d_jobs, n_jobs,
@@ -381,9 +385,12 @@ static int launch_pbs(tfa_ctx *ctx, const uint32_t *in_base, uint32_t in_stride,
     else if (variant == 4)
         hipLaunchKernelGGL(pbs_kernel<4>, dim3((n_jobs + 3) / 4), dim3(256), PbsGeom<4>::kLdsBytes, ctx->stream, in_base, in_stride, d_jobs, n_jobs,
                            ctx->d_bsk_f, ctx->d_tw, ctx->p.lwe_dimension, steps, ctx->d_big, ctx->big_stride, acc_out);
+    else if (variant == 2)
+        hipLaunchKernelGGL(pbs_lat_kernel<2>, dim3(n_jobs), dim3(256), LatGeom<2>::kLdsBytes, ctx->stream, in_base, in_stride, d_jobs, n_jobs,
+                           ctx->d_bsk_lat, ctx->d_tw_lat, ctx->p.lwe_dimension, steps, ctx->d_big, ctx->big_stride, acc_out);
     else
-        hipLaunchKernelGGL(pbs_lat_kernel, dim3(n_jobs), dim3(256), kLatLdsBytes, ctx->stream, in_base, in_stride, d_jobs, n_jobs, ctx->d_bsk_lat,
-                           ctx->d_tw_lat, ctx->p.lwe_dimension, steps, ctx->d_big, ctx->big_stride, acc_out);
+        hipLaunchKernelGGL(pbs_lat_kernel<1>, dim3(n_jobs), dim3(256), LatGeom<1>::kLdsBytes, ctx->stream, in_base, in_stride, d_jobs, n_jobs,
+                           ctx->d_bsk_lat, ctx->d_tw_lat, ctx->p.lwe_dimension, steps, ctx->d_big, ctx->big_stride, acc_out);
     HIPCHK(ctx, hipGetLastError());
     if (ctx->profiling) {
         HIPCHK(ctx, hipEventRecord(ep.b, ctx->stream));
@@ -492,6 +499,7 @@ extern "C" int tfa_stage_submit(tfa_ctx *ctx, const tfa_gate *gates, uint32_t co
     }
     int rc = ensure_jobs(ctx, total);
     if (rc) return rc;
+    if (ctx->trace) fprintf(stderr, "tfa stage: gates=%u pbs=%u ks=%u lin=%u\n", count, n_pbs, n_ks, n_lin);
     rc = ensure_big(ctx, n_pbs);
     if (rc) return rc;
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_jobs, h, total, hipMemcpyHostToDevice, ctx->stream));

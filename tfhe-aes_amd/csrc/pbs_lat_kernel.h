@@ -23,10 +23,17 @@ constexpr int kLatFftElems = 320;                       // 256 points, one c64 o
 constexpr int kLatFftBytes = kLatFftElems * 16;         // 5120
 constexpr int kLatWaveBytes = 2 * kLatFftBytes;         // one transform buffer per level; the first doubles as rotation buffer
 constexpr int kLatRedOffset = 4 * kLatWaveBytes;        // 40960
-constexpr int kLatRedElems = 2 * 4 * 2 * 4 * 64;        // spectra exchange [parity][polynomial][level][q][L]
-constexpr int kLatAOffset = kLatRedOffset + kLatRedElems * 16;
-constexpr int kLatLdsBytes = kLatAOffset + kABytes;     // 108160
-static_assert(kLatLdsBytes <= 163840, "LDS budget");
+constexpr int kLatSpecElems = 4 * 2 * 4 * 64;           // spectra exchange [polynomial][level][q][L], 32 KiB
+// PER_CU = 1: one workgroup per CU, the exchange alternates between two buffers (one barrier per step);
+// PER_CU = 2: two workgroups share a CU and hide each other's waits, one exchange buffer and a second
+// barrier per step so that both fit in the LDS
+template <int PER_CU>
+struct LatGeom {
+    static constexpr int kSpecBuffers = PER_CU == 1 ? 2 : 1;
+    static constexpr int kAOffset = kLatRedOffset + kSpecBuffers * kLatSpecElems * 16;
+    static constexpr int kLdsBytes = kAOffset + kABytes;  // 108160 / 75392
+};
+static_assert(LatGeom<1>::kLdsBytes <= 163840 && 2 * LatGeom<2>::kLdsBytes <= 163840, "LDS budget");
 static_assert(kN * 4 <= kLatFftBytes, "rotation buffer must fit in a transform buffer");
 constexpr int kLatConvertLdsBytes = 4 * kLatFftBytes;
 
@@ -121,7 +128,8 @@ __device__ __forceinline__ size_t bsk_lat_index(uint32_t i, int lv, int p, int c
     return (((((size_t)i * kLevels + lv) * kK1 + p) * kK1 + c) * 4 + q) * 64;
 }
 
-__global__ void __launch_bounds__(256, 1)
+template <int PER_CU>
+__global__ void __launch_bounds__(256, PER_CU)
     pbs_lat_kernel(const uint32_t *__restrict__ in_base, uint32_t in_stride, const PbsJob *__restrict__ jobs, uint32_t n_jobs,
                    const c64 *__restrict__ bsk_lat, const c64 *__restrict__ tw_lat, uint32_t n, uint32_t steps, uint32_t *__restrict__ big_out,
                    uint32_t big_stride, uint32_t *__restrict__ acc_out) {
@@ -133,7 +141,7 @@ __global__ void __launch_bounds__(256, 1)
     c64 *fb = reinterpret_cast<c64 *>(lds + w * kLatWaveBytes);
     uint32_t *rot = reinterpret_cast<uint32_t *>(fb);
     c64 *red = reinterpret_cast<c64 *>(lds + kLatRedOffset);
-    uint16_t *a_tilde = reinterpret_cast<uint16_t *>(lds + kLatAOffset);
+    uint16_t *a_tilde = reinterpret_cast<uint16_t *>(lds + LatGeom<PER_CU>::kAOffset);
 
     // gate linear combination + modulus switch
     const PbsJob jb = jobs[job];
@@ -194,9 +202,10 @@ __global__ void __launch_bounds__(256, 1)
         wave_lds_fence();
         lat_forward<2>(zr, zi, T, fb, L);
 
-        // publish both spectra.  The buffer alternates with the step parity: a wave can only write step i + 2's
-        // spectra after the barrier of step i + 1, which every wave passes after it has read step i's.
-        c64 *sp = red + (i & 1) * (kLatRedElems / 2);
+        // publish both spectra.  With two buffers they alternate with the step parity: a wave can only write
+        // step i + 2's spectra after the barrier of step i + 1, which every wave passes after it has read step
+        // i's.  With one buffer a second barrier below separates this step's reads from the next step's writes.
+        c64 *sp = red + (LatGeom<PER_CU>::kSpecBuffers == 2 ? (i & 1) * kLatSpecElems : 0);
 #pragma unroll
         for (int lv = 0; lv < 2; lv++)
 #pragma unroll
@@ -231,8 +240,13 @@ __global__ void __launch_bounds__(256, 1)
                     oui[0][q] += f.x * b.y + f.y * b.x;
                 }
         }
+        if (LatGeom<PER_CU>::kSpecBuffers == 1) __syncthreads();
         // next step's key words replace the ones just consumed; they have almost a whole step to arrive
+#ifdef TFA_EXP_NODMA  // timing experiment: the first step's key words are reused (results are garbage)
+        if (false) {
+#else
         if (i + 1 < n_steps) {
+#endif
 #pragma unroll
             for (int lv = 0; lv < 2; lv++)
 #pragma unroll
