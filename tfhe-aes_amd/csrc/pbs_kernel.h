@@ -295,18 +295,22 @@ __device__ __forceinline__ double reduce_scatter_rows(double p0, double p1, doub
 __device__ __forceinline__ uint32_t modswitch_2n(uint32_t x) {  // closest multiple of q/1024, index mod 1024
     return (((x >> 21) + 1u) >> 1) & 1023u;
 }
-// signed decomposition, base 2^10, 2 levels: d1 pairs with q/2^10, d2 with q/2^20
+// Signed decomposition, base B = 2^10, 2 levels, of the closest multiple of q / 2^20: d1 pairs with q / 2^10
+// (key level 0), d2 with q / 2^20 (key level 1).  tfhe-rs extracts digits from the least significant end:
+// res = state mod B, state = state / B, carry = res > B/2 || (res == B/2 && bit 9 of state), digit = res - carry * B.
+// Written on the whole word: the carry is bit 10 of res + 511 + bit 19 of the state.
+__device__ __forceinline__ uint32_t decompose_closest(uint32_t x) { return (((x >> 11) + 1u) >> 1) & 0xFFFFFu; }
+__device__ __forceinline__ void decompose_low_of(uint32_t s, int &d2, uint32_t &state) {  // s = decompose_closest(x)
+    const uint32_t u = s + 511u + (s >> 19);
+    d2 = (int)(s - (u & ~1023u));
+    state = u >> 10;  // <= 1024
+}
+// second digit: the state above it is 0 or 1 (bit 9 clear), and 1 only with res == 0
+__device__ __forceinline__ int decompose_high(uint32_t state) { return (int)(state - ((state + 511u) & ~1023u)); }
 __device__ __forceinline__ void decompose2(uint32_t x, int &d1, int &d2) {
-    uint32_t state = (((x >> 11) + 1u) >> 1) & 0xFFFFFu;
-    uint32_t res = state & 1023u;
-    state >>= 10;
-    uint32_t carry = (((res - 1u) | state) & res) >> 9;
-    state += carry;
-    d2 = (int)res - (int)(carry << 10);
-    res = state & 1023u;
-    state >>= 10;
-    carry = (((res - 1u) | state) & res) >> 9;
-    d1 = (int)res - (int)(carry << 10);
+    uint32_t state;
+    decompose_low_of(decompose_closest(x), d2, state);
+    d1 = decompose_high(state);
 }
 // Nearest integer mod 2^32 of an inverse-transform output.  |x| < 2^51 always holds here: x is a sum of
 // 4096 products of a digit (|d| <= 2^9) and a key word (|w| < 2^31), whose standard deviation is about
@@ -458,8 +462,8 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
 #pragma unroll
         for (int m = 0; m < 32; m++) rot[g * kRotStride + 16 * m + t] = acc[m];
         wave_lds_fence();
-        uint32_t dig[32];   // 8 waves: level-1 digit in the low half, level-2 digit in the high half
-        double f1r[16], f1i[16], f2r[16], f2i[16];  // 4 waves: both levels' digits, already as doubles
+        uint32_t dig[32];                           // 8 waves: level-1 digit in the low half, level-2 digit in the high half
+        double f1r[16], f1i[16], f2r[16], f2i[16];  // 4 waves: both levels' digits
 #pragma unroll
         for (int m = 0; m < 32; m++) {
             int jj = 16 * m + t - a;  // (-1024, 512]
@@ -469,12 +473,9 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
             decompose2(v - acc[m], d1, d2);
             if constexpr (WAVES == 8) {
                 dig[m] = ((uint32_t)d1 & 0xFFFFu) | ((uint32_t)d2 << 16);
-            } else if (m < 16) {
-                f1r[m] = (double)d1;
-                f2r[m] = (double)d2;
             } else {
-                f1i[m - 16] = (double)d1;
-                f2i[m - 16] = (double)d2;
+                (m < 16 ? f1r[m & 15] : f1i[m & 15]) = (double)d1;
+                (m < 16 ? f2r[m & 15] : f2i[m & 15]) = (double)d2;
             }
         }
         TFA_STAMP(1);  // rotate + decompose
