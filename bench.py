@@ -10,7 +10,9 @@ Prints one JSON line: metric/value per the driver contract, plus
                  mean kernel time from HIP events on the engine's stream) against the fp64 peak
   cpu_baseline - the CPU oracle (C restatement, fp64 FFT engine, OpenMP over gates) on a bounded
                  sample of the same workload, timed on this node's host cores (rank 0, N=1 only)
-  aes          - seconds for one homomorphic AES-128 ECB block (FIPS-197 App. B), checked
+  aes          - seconds for one homomorphic AES-128 ECB block (FIPS-197 App. B, latency), and the
+                 sharded case: 8 independent CTR blocks per GPU (SP 800-38A F.5.1 extended), keys
+                 replicated, outputs gathered over the process group; both checked against the standard
 """
 import argparse
 import json
@@ -77,6 +79,41 @@ def aes_block(device):
     keys.close()
     return {"ecb_encrypt_block_s": round(dt, 4), "correct": ok, "stages": after["stages"] - before["stages"],
             "gates": after["gates"] - before["gates"], "pbs": 127872}
+
+
+def aes_ctr_sharded(device, rank, world, coll_dev, blocks_per_gpu=8):
+    """blocks_per_gpu * world independent CTR blocks, block b on rank b mod world (BASELINE configs[4] shape).
+    Returns (seconds for this rank's shard, gathered output ciphertexts or None)."""
+    import torch.distributed as dist
+    from tfhe_aes_amd import host as H
+    from tfhe_aes_amd import shard
+    n_blocks = blocks_per_gpu * world
+    keys = H.gen_keys(SEED ^ 0x99, device)                     # same seed everywhere: replicated key material
+    rk = [H.Key.from_u8_enc(k, keys) for k in H.key_expansion_clear(bytes.fromhex("2b7e151628aed2a6abf7158809cf4f3c"))]
+    ctr0 = int("f0f1f2f3f4f5f6f7f8f9fafbfcfdfeff", 16)
+    nist_pt = ["6bc1bee22e409f96e93d7e117393172a", "ae2d8a571e03ac9c9eb76fac45af8e51", "30c81c46a35ce411e5fbc1191a0a52ef",
+               "f69f2445df4f9b17ad2b417be66c3710"]
+    rng = np.random.default_rng(4242)
+    pts = [bytes.fromhex(nist_pt[b]) if b < 4 else rng.integers(0, 256, 16, dtype=np.uint8).tobytes() for b in range(n_blocks)]
+    mine = shard.block_partition(n_blocks, world, rank)
+    counters = [H.State.from_u128_enc((ctr0 + b) % (1 << 128), keys) for b in mine]
+    states = [H.State.from_u8_enc(pts[b], keys) for b in mine]
+    keys.flush()
+    if world > 1:
+        dist.barrier()
+    t = time.perf_counter()
+    H.CTR(rk, counters, len(mine)).encrypt(states)
+    keys.flush()
+    dt = time.perf_counter() - t
+    local = np.stack([st.read() for st in states])
+    out = shard.gather_blocks(local, n_blocks, device=coll_dev) if world > 1 else local
+    ok = None
+    if rank == 0:
+        nist_ct = ["874d6191b620e3261bef6864990db6ce", "9806f66b7970fdff8617187bb9fffdff", "5ae4df3edbd5d35e5b4f09020db03eab",
+                   "1e031dda2fbe03d1792170a0f3009cee"]
+        ok = all(H.State.import_lwe(out[b], keys).decrypt_to_u8().hex() == nist_ct[b] for b in range(4))
+    keys.close()
+    return dt, n_blocks, ok
 
 
 def main():
@@ -173,9 +210,19 @@ def main():
         if gathered is not None:
             line["gathered_ciphertexts"] = int(gathered.shape[0] * gathered.shape[1])
     ctx.close()
+    if not args.no_aes:
+        # every rank takes part: 8 CTR blocks per GPU, max time over ranks
+        dt, n_blocks, ok = aes_ctr_sharded(local_rank, rank, world, coll_dev)
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        if rank == 0:
+            line["aes"] = {"ctr_blocks": n_blocks, "ctr_seconds": round(dt, 3), "ctr_s_per_block": round(dt / n_blocks, 4),
+                           "ctr_first_blocks_match_sp800_38a": ok, "sharding": f"block b on GPU b mod {world}, keys replicated, outputs gathered"}
     if rank == 0:
         if world == 1 and not args.no_aes:
-            line["aes"] = aes_block(local_rank)
+            line["aes"].update(aes_block(local_rank))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(p, lwe_sk, bsk, ksk)
         print(json.dumps(line), flush=True)
