@@ -35,6 +35,7 @@ struct tfa_ctx {
     c64 *d_bsk_f = nullptr;
     uint32_t *d_ksk = nullptr;
     c64 *d_tw = nullptr;
+    int8_t *d_ksk8 = nullptr;  // keyswitching key as signed byte planes for the int8 matrix cores (default parameter shape only)
     c64 *d_bsk_lat = nullptr;  // second copy of the Fourier key in the latency kernel's layout
     c64 *d_tw_lat = nullptr;
     uint32_t ksk_stride = 0;
@@ -57,6 +58,7 @@ struct tfa_ctx {
     tfa_stats stats{};
     bool profiling = false;
     uint32_t n_cus = 256;
+    bool ks_valu = false;  // TFA_KS_VALU=1: keep the keyswitch on the vector ALUs (the generic-parameter path; for comparison)
     bool trace = false;   // TFA_TRACE=1: one stderr line per submitted stage
     int force_waves = 0;  // 0 = choose per launch; 1 / 2 (latency kernel, workgroups per CU), 4 or 8 pins the kernel variant (TFA_PBS_WAVES, for experiments)
     std::vector<EventPair> pending;
@@ -188,6 +190,7 @@ extern "C" int tfa_ctx_create(const tfa_params *p, int hip_device, tfa_ctx **out
     HIPCHK(ctx, hipGetDeviceProperties(&prop, hip_device));
     if (prop.multiProcessorCount > 0) ctx->n_cus = (uint32_t)prop.multiProcessorCount;
     if (const char *t = getenv("TFA_TRACE")) ctx->trace = atoi(t) != 0;
+    if (const char *t = getenv("TFA_KS_VALU")) ctx->ks_valu = atoi(t) != 0;
     if (const char *w = getenv("TFA_PBS_WAVES")) ctx->force_waves = (atoi(w) == 8 || atoi(w) == 4 || atoi(w) == 2 || atoi(w) == 1) ? atoi(w) : 0;
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     // per-lane twiddles e^{i pi t (1 + 4 r)/512}, [r][t]
@@ -228,6 +231,7 @@ extern "C" int tfa_ctx_destroy(tfa_ctx *ctx) {
     hipFree(ctx->d_bsk_f);
     hipFree(ctx->d_ksk);
     hipFree(ctx->d_tw);
+    hipFree(ctx->d_ksk8);
     hipFree(ctx->d_bsk_lat);
     hipFree(ctx->d_tw_lat);
     hipFree(ctx->d_pool);
@@ -259,6 +263,15 @@ extern "C" int tfa_keys_upload(tfa_ctx *ctx, const uint32_t *bsk, const uint32_t
     HIPCHK(ctx, hipMemset(ctx->d_ksk, 0, (size_t)kN_ * p.ks_level * ctx->ksk_stride * sizeof(uint32_t)));
     HIPCHK(ctx, hipMemcpy2D(ctx->d_ksk, ctx->ksk_stride * sizeof(uint32_t), ksk, (n + 1) * sizeof(uint32_t), (n + 1) * sizeof(uint32_t),
                             (size_t)kN_ * p.ks_level, hipMemcpyHostToDevice));
+    // byte planes of the KSK for the matrix-core keyswitch
+    if (p.ks_level == 5 && p.ks_base_log <= 8 && kN_ % kKsmCoefs == 0) {
+        const uint32_t n_kb = kN_ / kKsmCoefs, n_tiles = (n + 1 + kKsmCols - 1) / kKsmCols;
+        const size_t frags = (size_t)n_tiles * n_kb * 5 * 4 * 4 * 64;
+        if (!ctx->d_ksk8) HIPCHK(ctx, hipMalloc(&ctx->d_ksk8, frags * 16));
+        hipLaunchKernelGGL(ksk_to_planes_kernel<5>, dim3((unsigned)((frags + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ksk, ctx->ksk_stride, n, n_kb,
+                           n_tiles, ctx->d_ksk8);
+        HIPCHK(ctx, hipGetLastError());
+    }
     // BSK: upload the standard domain, transform on the device
     uint32_t *d_std = nullptr;
     HIPCHK(ctx, hipMalloc(&d_std, bsk_words * sizeof(uint32_t)));
@@ -410,6 +423,20 @@ static int launch_ks(tfa_ctx *ctx, const KsJob *d_jobs, uint32_t n_jobs, uint32_
         HIPCHK(ctx, hipEventRecord(ep.a, ctx->stream));
     }
     const uint32_t big_dim = p.glwe_dimension * p.polynomial_size;
+    // From one workgroup tile of gates per CU upwards the int8 matrix cores win (3.7 ms against 29 ms for 65536 gates);
+    // narrower stages are latency-bound and stay on the vector kernels, which split the key stream over all CUs.
+    if (ctx->d_ksk8 && !ctx->ks_valu && n_jobs >= 256) {
+        hipLaunchKernelGGL(keyswitch_mfma_kernel<5>, dim3((n_jobs + kKsmGates - 1) / kKsmGates, (p.lwe_dimension + 1 + kKsmCols - 1) / kKsmCols), dim3(256), 0,
+                           ctx->stream, ctx->d_big, ctx->big_stride, d_jobs, n_jobs, ctx->d_ksk8, p.lwe_dimension, big_dim, p.ks_base_log, out_base,
+                           out_stride);
+        HIPCHK(ctx, hipGetLastError());
+        if (ctx->profiling) {
+            HIPCHK(ctx, hipEventRecord(ep.b, ctx->stream));
+            ctx->pending.push_back(ep);
+        }
+        ctx->stats.ks_count += n_jobs;
+        return TFA_OK;
+    }
 #define KS_LAUNCH(TG, UNROLL, SPLIT)                                                                                                         \
     hipLaunchKernelGGL((keyswitch_kernel<TG, UNROLL>), dim3((n_jobs + TG - 1) / TG, SPLIT), dim3(832), kKsChunk *p.ks_level *TG * sizeof(int32_t), \
                        ctx->stream, ctx->d_big, ctx->big_stride, d_jobs, n_jobs, ctx->d_ksk, ctx->ksk_stride, p.lwe_dimension, big_dim,            \

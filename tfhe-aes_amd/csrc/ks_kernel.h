@@ -132,6 +132,148 @@ __global__ void keyswitch_init_kernel(const uint32_t *__restrict__ big, uint32_t
     }
 }
 
+// ---- keyswitch on the int8 matrix cores ------------------------------------------------------------
+// The keyswitch of a batch is an integer matrix product: [gates x (kN * levels)] signed digits (|d| <= 2^(base_log-1))
+// times the [kN * levels x (n+1)] key, mod 2^32.  Each 32-bit key word is recoded once, at upload, into four
+// signed bytes (word = sum_b byte_b * 2^(8b) mod 2^32); the four byte planes are multiplied separately by
+// v_mfma_i32_16x16x64_i8 into int32 accumulators (|sum| <= 7680 * 4 * 128 < 2^22, no overflow) and recombined
+// with shifts at the end, which is exact.
+// Workgroup = 4 waves = 128 gates x 64 output columns; wave w owns columns 16w..16w+15 (all four planes), as
+// 8 row tiles of 16 gates.  K runs over blocks of 64 input coefficients: the block's digits are decomposed
+// into LDS once ([level][gate][64 coefficients] int8, rows padded to 80 bytes: conflict-free 16-byte reads),
+// then one MFMA K-step per level.  Key layout ksk8: [column tile][K block][level][wave][plane][lane][16 bytes],
+// byte j of lane l = coefficient 64 kb + 16 (l >> 4) + j, column 16 w + (l & 15): the same (lane, byte) -> k
+// assignment as the digit fragments, so the hardware's k order inside a step does not matter.
+constexpr int kKsmGates = 128, kKsmCols = 64, kKsmCoefs = 64, kKsmRowBytes = 80;
+typedef int ksm_v4i __attribute__((ext_vector_type(4)));
+
+template <int LEVELS>
+__global__ void __launch_bounds__(256, 2)
+    keyswitch_mfma_kernel(const uint32_t *__restrict__ big, uint32_t big_stride, const KsJob *__restrict__ jobs, uint32_t n_jobs,
+                          const int8_t *__restrict__ ksk8, uint32_t n, uint32_t big_dim, uint32_t base_log, uint32_t *__restrict__ out_base,
+                          uint32_t out_stride) {
+    __shared__ __align__(16) int8_t digs[LEVELS * kKsmGates * kKsmRowBytes];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t g0 = blockIdx.x * kKsmGates, ntile = blockIdx.y;
+    const uint32_t n_kb = big_dim / kKsmCoefs;
+    const uint32_t rep = base_log * LEVELS, non_rep = 32 - rep, mask = (1u << base_log) - 1u;
+    ksm_v4i acc[8][4];
+#pragma unroll
+    for (int m = 0; m < 8; m++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[m][b] = ksm_v4i{0, 0, 0, 0};
+
+    // this thread's decomposition tasks: gate (task >> 4), coefficients 4 * (task & 15) .. + 3 of the block
+    uint32_t task_a[8], task_b[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const uint32_t gi = g0 + ((threadIdx.x + 256 * r) >> 4);
+        task_a[r] = task_b[r] = kNoSlot;
+        if (gi < n_jobs) {
+            task_a[r] = jobs[gi].a;
+            task_b[r] = jobs[gi].b;
+        }
+    }
+    for (uint32_t kb = 0; kb < n_kb; kb++) {
+        __syncthreads();  // the previous block's digit reads are done
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint32_t task = threadIdx.x + 256 * r, gl = task >> 4, quad = task & 15, i0 = kb * kKsmCoefs + quad * 4;
+            uint4 x = uint4{0, 0, 0, 0};
+            if (task_a[r] != kNoSlot) {
+                x = *reinterpret_cast<const uint4 *>(big + (size_t)task_a[r] * big_stride + i0);
+                if (task_b[r] != kNoSlot) {
+                    const uint4 y = *reinterpret_cast<const uint4 *>(big + (size_t)task_b[r] * big_stride + i0);
+                    x.x += y.x;
+                    x.y += y.y;
+                    x.z += y.z;
+                    x.w += y.w;
+                }
+            }
+            const uint32_t xs[4] = {x.x, x.y, x.z, x.w};
+            uint32_t packed[LEVELS];
+#pragma unroll
+            for (int lv = 0; lv < LEVELS; lv++) packed[lv] = 0;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                uint32_t state = ((xs[c] >> (non_rep - 1)) + 1u) >> 1;
+                state &= (1u << rep) - 1u;
+#pragma unroll
+                for (int lv = LEVELS; lv >= 1; lv--) {
+                    const uint32_t res = state & mask;
+                    state >>= base_log;
+                    const uint32_t carry = (((res - 1u) | state) & res) >> (base_log - 1);
+                    state += carry;
+                    const uint32_t digit = res - (carry << base_log);  // two's complement
+                    packed[lv - 1] |= (digit & 0xFFu) << (8 * c);
+                }
+            }
+#pragma unroll
+            for (int lv = 0; lv < LEVELS; lv++)
+                *reinterpret_cast<uint32_t *>(digs + (lv * kKsmGates + gl) * kKsmRowBytes + quad * 4) = packed[lv];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int lv = 0; lv < LEVELS; lv++) {
+            const ksm_v4i *kp = reinterpret_cast<const ksm_v4i *>(ksk8) + ((((size_t)ntile * n_kb + kb) * LEVELS + lv) * 4 + wave) * 4 * 64 + lane;
+            ksm_v4i bq[4];
+#pragma unroll
+            for (int b = 0; b < 4; b++) bq[b] = kp[b * 64];
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const ksm_v4i a = *reinterpret_cast<const ksm_v4i *>(digs + (lv * kKsmGates + 16 * m + (lane & 15)) * kKsmRowBytes + (lane >> 4) * 16);
+#pragma unroll
+                for (int b = 0; b < 4; b++) acc[m][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bq[b], acc[m][b], 0, 0, 0);
+            }
+        }
+    }
+    // accumulator tile: column = lane & 15, row = 4 * (lane >> 4) + register
+    const uint32_t col = ntile * kKsmCols + wave * 16 + (lane & 15);
+    if (col > n) return;
+#pragma unroll
+    for (int m = 0; m < 8; m++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t gi = g0 + 16 * m + 4 * (lane >> 4) + r;
+            if (gi >= n_jobs) continue;
+            const KsJob jb = jobs[gi];
+            uint32_t v = 0u - ((uint32_t)acc[m][0][r] + ((uint32_t)acc[m][1][r] << 8) + ((uint32_t)acc[m][2][r] << 16) + ((uint32_t)acc[m][3][r] << 24));
+            if (col == n) {
+                v += big[(size_t)jb.a * big_stride + big_dim] + jb.cst;
+                if (jb.b != kNoSlot) v += big[(size_t)jb.b * big_stride + big_dim];
+            }
+            out_base[(size_t)jb.out * out_stride + col] = v;
+        }
+}
+
+// u32 key [kN * levels][ksk_stride] -> signed byte planes in keyswitch_mfma_kernel's layout; one thread per 16-byte fragment
+template <int LEVELS>
+__global__ void ksk_to_planes_kernel(const uint32_t *__restrict__ ksk, uint32_t ksk_stride, uint32_t n, uint32_t n_kb, uint32_t n_tiles,
+                                     int8_t *__restrict__ ksk8) {
+    const size_t frag = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // ((((ntile * n_kb + kb) * LEVELS + lv) * 4 + wave) * 4 + plane) * 64 + lane
+    const size_t total = (size_t)n_tiles * n_kb * LEVELS * 4 * 4 * 64;
+    if (frag >= total) return;
+    const uint32_t lane = frag & 63, plane = (frag >> 6) & 3, wave = (frag >> 8) & 3;
+    size_t rest = frag >> 10;
+    const uint32_t lv = rest % LEVELS;
+    rest /= LEVELS;
+    const uint32_t kb = rest % n_kb, ntile = rest / n_kb;
+    const uint32_t col = ntile * kKsmCols + wave * 16 + (lane & 15);
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const uint32_t coef = kb * kKsmCoefs + (lane >> 4) * 16 + j;
+        uint32_t x = col <= n ? ksk[((size_t)coef * LEVELS + lv) * ksk_stride + col] : 0u;
+        uint32_t byte = 0;
+        for (uint32_t b = 0; b <= plane; b++) {  // signed-digit recoding, base 256
+            byte = x & 0xFFu;
+            x = (x - (uint32_t)(int32_t)(int8_t)byte) >> 8;
+        }
+        w[j >> 2] |= byte << (8 * (j & 3));
+    }
+    reinterpret_cast<uint4 *>(ksk8)[frag] = uint4{w[0], w[1], w[2], w[3]};
+}
+
 // dst = coef * src on whole ciphertexts (NOT: coef = -1, COPY: coef = +1)
 struct LinJob {
     uint32_t src, dst;

@@ -49,6 +49,15 @@ __global__ void __launch_bounds__(256) k_rate(double* out, int iters) {
         x0 = fma(x0, c, d); u0 += u1; x1 = fma(x1, c, d); u1 ^= u2; x2 = fma(x2, c, d); u2 += u3; x3 = fma(x3, c, d); u3 ^= u0;
         x4 = fma(x4, c, d); u0 += u2; x5 = fma(x5, c, d); u1 ^= u3; x6 = fma(x6, c, d); u2 += u0; x7 = fma(x7, c, d); u3 ^= u1;
       }
+    } else if (MODE == 6) {  // v_dot4c_i32_i8
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        u0 = __builtin_amdgcn_sdot4(u1, u2, u0, false); u1 = __builtin_amdgcn_sdot4(u2, u3, u1, false);
+        u2 = __builtin_amdgcn_sdot4(u3, u0, u2, false); u3 = __builtin_amdgcn_sdot4(u0, u1, u3, false);
+      }
+    } else if (MODE == 7) {  // v_mad_u32_u24 / plain add
+#pragma unroll
+      for (int j = 0; j < 16; j++) { u0 += u1; u1 ^= u2; u2 += u3; u3 ^= u0; }
     } else if (MODE == 4) {  // v_mul_lo_u32
 #pragma unroll
       for (int j = 0; j < 16; j++) { u0 = u0 * u1 + 1; u1 = u1 * u2 + 1; u2 = u2 * u3 + 1; u3 = u3 * u0 + 1; }
@@ -90,6 +99,7 @@ int main() {
     printf("--- %d wave(s) per SIMD\n", mult);
     rate<0>("fma_f64", 64, blocks, th); rate<1>("add_f64", 64, blocks, th); rate<3>("mul_f64", 64, blocks, th);
     rate<2>("permlane_swap", 64, blocks, th); rate<4>("mul_lo_u32", 64, blocks, th); rate<5>("mix_fma_int", 128, blocks, th);
+    rate<6>("dot4_i8", 64, blocks, th); rate<7>("int_add_xor", 64, blocks, th);
   }
   return 0;
 }
