@@ -51,6 +51,44 @@ def test_keyswitch_tile_sizes_bit_exact(gpu_ctx, oracle, okeys):
         assert (sdiff(gpu_ctx.keyswitch_batch(big2)[0], got[0])[:-1] == 0).all()
 
 
+def test_keyswitch_vector_path_bit_exact(oracle, okeys):
+    """The vector-ALU keyswitch kernels (generic parameters; narrow stages in production) at the batch sizes
+    where production would pick the matrix-core kernel: pinned with TFA_KS_VALU=1."""
+    import os
+    os.environ["TFA_KS_VALU"] = "1"
+    try:
+        ctx = E.Context(E.default_params(), 0)
+    finally:
+        del os.environ["TFA_KS_VALU"]
+    try:
+        ctx.keys_upload(okeys[2], okeys[3])
+        rng = np.random.default_rng(3)
+        for count in (300, 2500, 8200):
+            big = rng.integers(0, 2**32, (count, ctx.big + 1), dtype=np.uint64).astype(np.uint32)
+            got = ctx.keyswitch_batch(big)
+            for i in (0, count // 3, count - 1):
+                assert (got[i] == oracle.keyswitch(okeys[3], big[i])).all()
+    finally:
+        ctx.close()
+
+
+def test_keyswitch_matrix_core_tile_edges(gpu_ctx, oracle, okeys):
+    """Matrix-core keyswitch at its tile edges: exactly one tile of 128 gates short of / past a boundary, extreme
+    inputs (all-ones rounds up into the top digit and wraps), every row checked on the smallest batch."""
+    rng = np.random.default_rng(4)
+    for count in (256, 257, 383, 385):
+        big = rng.integers(0, 2**32, (count, gpu_ctx.big + 1), dtype=np.uint64).astype(np.uint32)
+        big[0] = 0xFFFFFFFF
+        big[1] = 0x80000000
+        big[2] = 0x7FFFFFFF
+        big[3] = 0x00010000
+        big[count - 1, ::7] = 0xFFFF0000
+        got = gpu_ctx.keyswitch_batch(big)
+        rows = range(count) if count == 256 else (0, 1, 2, 3, 127, 128, 255, 256, count - 1)
+        for i in rows:
+            assert (got[i] == oracle.keyswitch(okeys[3], big[i])).all(), (count, i)
+
+
 def test_blind_rotation_prefix_bit_exact(gpu_ctx, oracle, okeys):
     """Accumulator after 0, 1, 2 and 9 external products against the exact-integer oracle."""
     cts = oracle.encrypt_bits(okeys[0], 77, 0, np.array([0, 1, 1], np.uint8))

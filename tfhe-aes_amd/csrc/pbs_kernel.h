@@ -47,12 +47,16 @@ constexpr int kWavePrivBytes = kWaveLdsBytes + kABytes;
 constexpr int kTwBytes = 4096;                   // per-lane twiddle table shared by all waves
 // Bootstrapping-key ring: the Fourier GGSW of one blind-rotation step (128 KiB) streams through LDS
 // in 8 chunks of 16 KiB (two frequency groups k2 each), filled by LDS-DMA and shared by all waves.
-constexpr int kChunkBytes = 16384;
-constexpr int kChunksPerStep = 8;
+#ifndef TFA_RING8_ROWS
+#define TFA_RING8_ROWS 16
+#endif
 template <int WAVES>
 struct PbsGeom {
-    static constexpr int kSlots = WAVES == 8 ? 4 : 5;
-    static constexpr int kRowsPerWave = 16 / WAVES;  // 1 KiB DMA rows each wave issues per chunk
+    static constexpr int kChunkRows = WAVES == 8 ? TFA_RING8_ROWS : 16;  // 1 KiB key rows per chunk
+    static constexpr int kChunkBytes = kChunkRows * 1024;
+    static constexpr int kChunksPerStep = 128 / kChunkRows;
+    static constexpr int kSlots = WAVES == 8 ? 64 / kChunkRows : 5;
+    static constexpr int kRowsPerWave = kChunkRows / WAVES;  // DMA rows each wave issues per chunk
     // one wave per SIMD (WAVES == 4) has no partner wave to hide its LDS round trips, so it gets a second
     // transpose buffer and overlaps two transposes with each other and with arithmetic
     static constexpr int kTrBuffers = WAVES == 8 ? 1 : 2;
@@ -60,6 +64,7 @@ struct PbsGeom {
     static constexpr int kTwOffset = WAVES * kWaveBytes;
     static constexpr int kRingOffset = kTwOffset + kTwBytes;
     static constexpr int kLdsBytes = kRingOffset + kSlots * kChunkBytes;
+    static_assert(kSlots >= 2, "ring needs two slots");
 };
 constexpr int kConvertWaves = 4;
 constexpr int kConvertLdsBytes = kConvertWaves * kWavePrivBytes;
@@ -329,9 +334,11 @@ __device__ __forceinline__ size_t bsk_index(uint32_t i, int lv, int k2, int c) {
 // level of four frequency groups (each level is reduced on its own, which halves the live registers).
 template <int WAVES>
 __device__ __forceinline__ size_t chunk_row_index(uint32_t chunk, int row) {
-    const uint32_t i = chunk / kChunksPerStep, q = chunk % kChunksPerStep;
+    using G = PbsGeom<WAVES>;
+    const uint32_t i = chunk / G::kChunksPerStep, q = chunk % G::kChunksPerStep;
     if constexpr (WAVES == 8) {
-        return bsk_index(i, q >> 2, 4 * (q & 3) + (row >> 2), row & 3);
+        constexpr int kPerLevel = G::kChunksPerStep / 2, kGroups = G::kChunkRows / 4;  // chunks per level, frequency groups per chunk
+        return bsk_index(i, q / kPerLevel, kGroups * (q % kPerLevel) + (row >> 2), row & 3);
     } else {
         return bsk_index(i, (row >> 2) & 1, 2 * q + (row >> 3), row & 3);
     }
@@ -343,7 +350,7 @@ __device__ __forceinline__ void ring_issue(const c64 *bsk_f, uint32_t chunk, uns
 #ifdef TFA_EXP_NODMA  // timing experiment: no key traffic at all (results are garbage)
     return;
 #endif
-    unsigned char *dst = ring + (chunk % G::kSlots) * kChunkBytes;
+    unsigned char *dst = ring + (chunk % G::kSlots) * G::kChunkBytes;
 #pragma unroll
     for (int j = 0; j < G::kRowsPerWave; j++) {
         const int row = wave * G::kRowsPerWave + j;
@@ -363,12 +370,10 @@ __device__ __forceinline__ void ring_wait_own(uint32_t ch, uint32_t n_chunks) {
     if constexpr (WAVES == 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // at most the rows of the kSlots-2 younger chunks stay in flight
     if (ch + (G::kSlots - 2) < n_chunks) {
-        if constexpr ((G::kSlots - 2) * G::kRowsPerWave == 12)
-            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if constexpr ((G::kSlots - 2) * G::kRowsPerWave == 4)
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        constexpr int kInFlight = (G::kSlots - 2) * G::kRowsPerWave;
+        static_assert(kInFlight < 16, "vmcnt immediate below assumes the low four bits");
+        __builtin_amdgcn_s_waitcnt(0x0F70 | kInFlight);  // vmcnt(kInFlight), expcnt and lgkmcnt untouched
+        asm volatile("" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -377,7 +382,7 @@ template <int WAVES>
 __device__ __forceinline__ const c64 *ring_refill(const c64 *bsk_f, uint32_t ch, uint32_t n_chunks, unsigned char *ring, int wave, int lane) {
     using G = PbsGeom<WAVES>;
     if (ch + (G::kSlots - 1) < n_chunks) ring_issue<WAVES>(bsk_f, ch + (G::kSlots - 1), ring, wave, lane);
-    return reinterpret_cast<const c64 *>(ring + (ch % G::kSlots) * kChunkBytes) + lane;
+    return reinterpret_cast<const c64 *>(ring + (ch % G::kSlots) * G::kChunkBytes) + lane;
 }
 #ifdef TFA_EXP_NOBARRIER  // timing experiment: waves run free (results are garbage)
 #define TFA_RING_BARRIER() ((void)0)
@@ -447,7 +452,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
     }
 
     const uint32_t n_steps = steps < n ? steps : n;
-    const uint32_t n_chunks = n_steps * kChunksPerStep;
+    const uint32_t n_chunks = n_steps * G::kChunksPerStep;
     // every ordinary load above has been consumed; from here on the only vector-memory operations in
     // flight are the ring's LDS-DMA rows, so vmcnt counts them exactly
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -498,13 +503,14 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
                 TFA_STAMP(2);
                 fft_forward(fr, fi, twl, tr, g, t);
                 TFA_STAMP(3);  // forward transform
+                constexpr int kPerLevel = G::kChunksPerStep / 2, kGroups = G::kChunkRows / 4;
 #pragma unroll
-                for (int qq = 0; qq < 4; qq++) {
-                    TFA_RING_ACQUIRE(slot, i * kChunksPerStep + lv * 4 + qq)
+                for (int qq = 0; qq < kPerLevel; qq++) {
+                    TFA_RING_ACQUIRE(slot, i * G::kChunksPerStep + lv * kPerLevel + qq)
                     TFA_STAMP(4);  // ring wait + barrier + refill issue
 #pragma unroll
-                    for (int kq = 0; kq < 4; kq++) {
-                        const int k2 = 4 * qq + kq;
+                    for (int kq = 0; kq < kGroups; kq++) {
+                        const int k2 = kGroups * qq + kq;
                         double pr[4], pi[4];
 #pragma unroll
                         for (int c = 0; c < 4; c++) {
@@ -525,14 +531,14 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
             // latency and the barrier hide behind the products of the previous chunk
             c64 kb[2][16];
             {
-                TFA_RING_ACQUIRE(slot, i * kChunksPerStep)
+                TFA_RING_ACQUIRE(slot, i * G::kChunksPerStep)
 #pragma unroll
                 for (int r = 0; r < 16; r++) kb[0][r] = slot[r * 64];
             }
 #pragma unroll
-            for (int q = 0; q < kChunksPerStep; q++) {
-                if (q + 1 < kChunksPerStep) {
-                    TFA_RING_ACQUIRE(slot, i * kChunksPerStep + q + 1)
+            for (int q = 0; q < G::kChunksPerStep; q++) {
+                if (q + 1 < G::kChunksPerStep) {
+                    TFA_RING_ACQUIRE(slot, i * G::kChunksPerStep + q + 1)
 #pragma unroll
                     for (int r = 0; r < 16; r++) kb[(q + 1) & 1][r] = slot[r * 64];
                 }
