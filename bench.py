@@ -33,6 +33,18 @@ FP64_PEAK_TFLOPS = 78.6              # MI355X fp64 vector = matrix peak (datashe
 SEED = 0x5446484541455321
 
 
+def measured_traffic():
+    """HBM bytes per 65536-bootstrap launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (FETCH_SIZE doubled as gfx950 requires for 16-byte-per-lane reads, plus WRITE_SIZE; both in KiB).  Counters
+    cannot be collected inside a timed run, so this is the profile's number, or None without the file."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_pmc_summary.json")) as f:
+            c = json.load(f)["counters_current_kernels"]["tfa::pbs_kernel<8>"]
+        return int((2 * c["FETCH_SIZE@65536"] + c["WRITE_SIZE@65536"]) * 1024)
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(p, lwe_sk, bsk, ksk, budget_s=12.0):
     from oracle.pyoracle import NAND, XOR, Oracle
     o = Oracle()
@@ -204,7 +216,8 @@ def main():
                        "gates_per_step_per_gpu": G, "params": "n=805,k=3,N=512,pbs=2^10x2,ks=2^3x5", "parallelism": f"replicas x{world}, keys replicated"},
             "wrong_results": wrong,
             "roofline": {"bound": "mfma", "kernel": "pbs_kernel", "achieved": round(achieved, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP64_PEAK_TFLOPS, 4), "traffic": None, "kernel_ms": round(pbs_ms, 3),
+                         "frac": round(achieved / FP64_PEAK_TFLOPS, 4), "traffic": measured_traffic(), "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes, profiles/r1_pmc_summary.json)",
+                         "kernel_ms": round(pbs_ms, 3),
                          "keyswitch_kernel_ms": round(ks_ms, 3)},
         }
         if gathered is not None:
