@@ -25,6 +25,16 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
 
 
+def test_rust_sys_crate_declares_exactly_the_header():
+    """integration/rust/tfhe-aes-hip-sys/src/lib.rs (source only: no Rust toolchain here) names the same
+    functions as include/tfhe_aes_hip.h, and all of them are exported."""
+    text = open(os.path.join(ROOT, "integration", "rust", "tfhe-aes-hip-sys", "src", "lib.rs")).read()
+    rust = sorted(set(re.findall(r"pub fn (tfa_[a-z0-9_]+)\(", text)))
+    assert rust == declared("tfhe_aes_hip.h", "tfa")
+    lib = E.load_library()
+    assert all(hasattr(lib, n) for n in rust)
+
+
 def test_struct_layouts_match_header():
     assert C.sizeof(E.Gate) == 24 and C.sizeof(E.Params) == 48 and C.sizeof(E.Stats) == 64
     assert E.GATE_DTYPE.itemsize == 24
