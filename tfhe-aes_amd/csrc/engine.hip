@@ -385,11 +385,11 @@ static int launch_pbs(tfa_ctx *ctx, const uint32_t *in_base, uint32_t in_stride,
     // round of workgroups over all CUs, microseconds, MI355X):
     //   8 bootstraps per workgroup, two waves per SIMD (highest throughput)          13600 per 8 * CUs
     //   4 bootstraps per workgroup, one wave per SIMD                                  8600 per 4 * CUs
-    //   one bootstrap spread over the 4 waves of a workgroup, one workgroup per CU    3700 per CUs
-    //   the same with two workgroups per CU                                           5900 per 2 * CUs
+    //   one bootstrap spread over the 4 waves of a workgroup, one workgroup per CU    3500 per CUs
+    //   the same with two workgroups per CU                                           5500 per 2 * CUs
     const uint64_t cus = ctx->n_cus, P = n_jobs;
     const uint64_t t8 = ((P + 8 * cus - 1) / (8 * cus)) * 13600, t4 = ((P + 4 * cus - 1) / (4 * cus)) * 8600;
-    const uint64_t lat_rest = P % (2 * cus), t_lat = (P / (2 * cus)) * 5900 + (lat_rest == 0 ? 0 : lat_rest <= cus ? 3700 : 5900);
+    const uint64_t lat_rest = P % (2 * cus), t_lat = (P / (2 * cus)) * 5500 + (lat_rest == 0 ? 0 : lat_rest <= cus ? 3500 : 5500);
     int variant = t_lat <= t4 && t_lat <= t8 ? (P > cus ? 2 : 1) : (t8 < t4 ? 8 : 4);
     if (ctx->force_waves) variant = ctx->force_waves;
     if (variant == 8)

@@ -88,7 +88,26 @@ __device__ __forceinline__ void lat_exchange(double (&zr)[NL][4], double (&zi)[N
     wave_lds_fence();
 }
 
-// in: z[lv][q] = point n = L + 64 q of NL polynomials (folded, untwisted); out: z[lv][q] = frequency slot (q, L)
+// one level's stage: butterfly, twiddles, and (all but the last stage) the hand-over to the next stage's layout
+template <int NL>
+__device__ __forceinline__ void lat_stage(double (&zr)[NL][4], double (&zi)[NL][4], int lv, int s, const LatTwiddles &T, c64 *fb, int L) {
+    dft4<1>(zr[lv][0], zi[lv][0], zr[lv][1], zi[lv][1], zr[lv][2], zi[lv][2], zr[lv][3], zi[lv][3]);
+    if (s == 3) return;
+#pragma unroll
+    for (int r = 0; r < 3; r++) cmulc<1>(zr[lv][r + 1], zi[lv][r + 1], T.sr[s][r], T.si[s][r]);
+#pragma unroll
+    for (int r = 0; r < 4; r++) fb[lv * kLatFftElems + lat_pos(s, L, r)] = c64{zr[lv][r], zi[lv][r]};
+    wave_lds_fence();
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        c64 v = fb[lv * kLatFftElems + lat_pos(s + 1, L, q)];
+        zr[lv][q] = v.x;
+        zi[lv][q] = v.y;
+    }
+    wave_lds_fence();
+}
+// in: z[lv][q] = point n = L + 64 q of NL polynomials (folded, untwisted); out: z[lv][q] = frequency slot (q, L).
+// The levels alternate stage by stage, each in its own buffer, so one level's LDS round trip runs under the other's butterfly.
 template <int NL>
 __device__ __forceinline__ void lat_forward(double (&zr)[NL][4], double (&zi)[NL][4], const LatTwiddles &T, c64 *fb, int L) {
 #pragma unroll
@@ -96,17 +115,9 @@ __device__ __forceinline__ void lat_forward(double (&zr)[NL][4], double (&zi)[NL
 #pragma unroll
         for (int q = 0; q < 4; q++) cmulc<1>(zr[lv][q], zi[lv][q], T.twr[q], T.twi[q]);
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
+    for (int s = 0; s < 4; s++)
 #pragma unroll
-        for (int lv = 0; lv < NL; lv++) {
-            dft4<1>(zr[lv][0], zi[lv][0], zr[lv][1], zi[lv][1], zr[lv][2], zi[lv][2], zr[lv][3], zi[lv][3]);
-            if (s < 3) {
-#pragma unroll
-                for (int r = 0; r < 3; r++) cmulc<1>(zr[lv][r + 1], zi[lv][r + 1], T.sr[s][r], T.si[s][r]);
-            }
-        }
-        if (s < 3) lat_exchange<NL>(zr, zi, fb, s, s + 1, L);
-    }
+        for (int lv = 0; lv < NL; lv++) lat_stage<NL>(zr, zi, lv, s, T, fb, L);
 }
 
 // exact mirror of lat_forward (times 256)
@@ -231,13 +242,17 @@ __global__ void __launch_bounds__(256, PER_CU)
 #pragma unroll
         for (int p = 0; p < 4; p++) {
             if (p == w) continue;
+            c64 f[8];  // all eight reads of a polynomial in flight before the first product
+#pragma unroll
+            for (int e = 0; e < 8; e++) f[e] = sp[(p * 8 + e) * 64 + L];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int lv = 0; lv < 2; lv++)
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const c64 f = sp[((p * 2 + lv) * 4 + q) * 64 + L], b = key[lv][p][q];
-                    our[0][q] += f.x * b.x - f.y * b.y;
-                    oui[0][q] += f.x * b.y + f.y * b.x;
+                    const c64 b = key[lv][p][q];
+                    our[0][q] += f[lv * 4 + q].x * b.x - f[lv * 4 + q].y * b.y;
+                    oui[0][q] += f[lv * 4 + q].x * b.y + f[lv * 4 + q].y * b.x;
                 }
         }
         if (LatGeom<PER_CU>::kSpecBuffers == 1) __syncthreads();
