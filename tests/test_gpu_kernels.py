@@ -163,6 +163,22 @@ def test_every_kernel_variant_bit_exact(variant_ctx, oracle, okeys):
     assert (oracle.decrypt_bits(lwe_sk, out) == clear_gate(ops, a, b, c)).all()
 
 
+def test_batch_split_into_full_rounds_and_tail(gpu_ctx, oracle, okeys):
+    """A batch just over a whole round of the 8-wave kernel (8 bootstraps x 256 CUs) runs as that round plus a
+    separately mapped tail: outputs on both sides of the cut, for the extracted LWE and for the raw accumulator."""
+    lwe_sk, glwe_sk, bsk, ksk = okeys
+    count = 2048 + 37
+    bits = np.random.default_rng(31).integers(0, 2, count).astype(np.uint8)
+    cts = oracle.encrypt_bits(lwe_sk, 95, 0, bits)
+    got = gpu_ctx.bootstrap_batch(cts)
+    for g in (0, 2047, 2048, count - 1):
+        assert (got[g] == oracle.pbs(bsk, None, cts[g])).all(), g
+    assert ((np.array([oracle.phase(glwe_sk, x) for x in got[2040:2060]]) < 2**31) == bits[2040:2060].astype(bool)).all()
+    acc = gpu_ctx.blind_rotate_batch(cts, 2)
+    for g in (2047, 2048, count - 1):
+        assert (acc[g] == oracle.blind_rotate(bsk, None, cts[g], 2)).all(), g
+
+
 def clear_gate(op, a, b, c):
     return np.select([op == 0, op == 1, op == 2, op == 3, op == 4, op == 5, op == 6],
                      [a & b, 1 - (a & b), a | b, 1 - (a | b), a ^ b, 1 - (a ^ b), np.where(a == 1, b, c)]).astype(np.uint8)

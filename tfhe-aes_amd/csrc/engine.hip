@@ -381,29 +381,49 @@ static int launch_pbs(tfa_ctx *ctx, const uint32_t *in_base, uint32_t in_stride,
         HIPCHK(ctx, hipEventCreate(&ep.b));
         HIPCHK(ctx, hipEventRecord(ep.a, ctx->stream));
     }
-    // Four mappings, picked by which finishes this launch soonest on the device's CUs (measured time of one
-    // round of workgroups over all CUs, microseconds, MI355X):
+    // Four mappings, picked by which finishes soonest on the device's CUs (measured time of one round of
+    // workgroups over all CUs, microseconds, MI355X):
     //   8 bootstraps per workgroup, two waves per SIMD (highest throughput)          13600 per 8 * CUs
     //   4 bootstraps per workgroup, one wave per SIMD                                  8600 per 4 * CUs
     //   one bootstrap spread over the 4 waves of a workgroup, one workgroup per CU    3500 per CUs
     //   the same with two workgroups per CU                                           5500 per 2 * CUs
-    const uint64_t cus = ctx->n_cus, P = n_jobs;
-    const uint64_t t8 = ((P + 8 * cus - 1) / (8 * cus)) * 13600, t4 = ((P + 4 * cus - 1) / (4 * cus)) * 8600;
-    const uint64_t lat_rest = P % (2 * cus), t_lat = (P / (2 * cus)) * 5500 + (lat_rest == 0 ? 0 : lat_rest <= cus ? 3500 : 5500);
-    int variant = t_lat <= t4 && t_lat <= t8 ? (P > cus ? 2 : 1) : (t8 < t4 ? 8 : 4);
-    if (ctx->force_waves) variant = ctx->force_waves;
-    if (variant == 8)
-        hipLaunchKernelGGL(pbs_kernel<8>, dim3((n_jobs + 7) / 8), dim3(512), PbsGeom<8>::kLdsBytes, ctx->stream, in_base, in_stride, d_jobs, n_jobs,
-                           ctx->d_bsk_f, ctx->d_tw, ctx->p.lwe_dimension, steps, ctx->d_big, ctx->big_stride, acc_out);
-    else if (variant == 4)
-        hipLaunchKernelGGL(pbs_kernel<4>, dim3((n_jobs + 3) / 4), dim3(256), PbsGeom<4>::kLdsBytes, ctx->stream, in_base, in_stride, d_jobs, n_jobs,
-                           ctx->d_bsk_f, ctx->d_tw, ctx->p.lwe_dimension, steps, ctx->d_big, ctx->big_stride, acc_out);
-    else if (variant == 2)
-        hipLaunchKernelGGL(pbs_lat_kernel<2>, dim3(n_jobs), dim3(256), LatGeom<2>::kLdsBytes, ctx->stream, in_base, in_stride, d_jobs, n_jobs,
-                           ctx->d_bsk_lat, ctx->d_tw_lat, ctx->p.lwe_dimension, steps, ctx->d_big, ctx->big_stride, acc_out);
-    else
-        hipLaunchKernelGGL(pbs_lat_kernel<1>, dim3(n_jobs), dim3(256), LatGeom<1>::kLdsBytes, ctx->stream, in_base, in_stride, d_jobs, n_jobs,
-                           ctx->d_bsk_lat, ctx->d_tw_lat, ctx->p.lwe_dimension, steps, ctx->d_big, ctx->big_stride, acc_out);
+    // A batch that fills whole rounds of the 8-wave kernel and leaves a short tail runs the tail separately.
+    const uint64_t cus = ctx->n_cus;
+    auto best_single = [&](uint64_t P, int &variant) -> uint64_t {
+        const uint64_t t8 = ((P + 8 * cus - 1) / (8 * cus)) * 13600, t4 = ((P + 4 * cus - 1) / (4 * cus)) * 8600;
+        const uint64_t lat_rest = P % (2 * cus), t_lat = (P / (2 * cus)) * 5500 + (lat_rest == 0 ? 0 : lat_rest <= cus ? 3500 : 5500);
+        variant = t_lat <= t4 && t_lat <= t8 ? (P > cus ? 2 : 1) : (t8 < t4 ? 8 : 4);
+        return variant == 8 ? t8 : variant == 4 ? t4 : t_lat;
+    };
+    auto launch = [&](int variant, uint32_t first, uint32_t count) {
+        const PbsJob *jobs = d_jobs + first;
+        uint32_t *big = ctx->d_big + (size_t)first * ctx->big_stride;
+        uint32_t *acc = acc_out ? acc_out + (size_t)first * kK1 * kN : nullptr;
+        if (variant == 8)
+            hipLaunchKernelGGL(pbs_kernel<8>, dim3((count + 7) / 8), dim3(512), PbsGeom<8>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
+                               ctx->d_bsk_f, ctx->d_tw, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
+        else if (variant == 4)
+            hipLaunchKernelGGL(pbs_kernel<4>, dim3((count + 3) / 4), dim3(256), PbsGeom<4>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
+                               ctx->d_bsk_f, ctx->d_tw, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
+        else if (variant == 2)
+            hipLaunchKernelGGL(pbs_lat_kernel<2>, dim3(count), dim3(256), LatGeom<2>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
+                               ctx->d_bsk_lat, ctx->d_tw_lat, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
+        else
+            hipLaunchKernelGGL(pbs_lat_kernel<1>, dim3(count), dim3(256), LatGeom<1>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
+                               ctx->d_bsk_lat, ctx->d_tw_lat, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
+    };
+    int variant = 0, tail_variant = 0;
+    const uint64_t t_single = best_single(n_jobs, variant);
+    const uint32_t full = (uint32_t)((n_jobs / (8 * cus)) * (8 * cus));
+    if (ctx->force_waves) {
+        launch(ctx->force_waves, 0, n_jobs);
+    } else if (full > 0 && full < n_jobs && (full / (8 * cus)) * 13600 + best_single(n_jobs - full, tail_variant) < t_single) {
+        launch(8, 0, full);
+        HIPCHK(ctx, hipGetLastError());
+        launch(tail_variant, full, n_jobs - full);
+    } else {
+        launch(variant, 0, n_jobs);
+    }
     HIPCHK(ctx, hipGetLastError());
     if (ctx->profiling) {
         HIPCHK(ctx, hipEventRecord(ep.b, ctx->stream));
