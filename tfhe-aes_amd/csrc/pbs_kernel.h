@@ -58,7 +58,7 @@ struct PbsGeom {
     // 8 waves, split mode: each level is transformed, multiplied and reduced on its own; otherwise both levels
     // are transformed first and multiplied and reduced together (half the row reductions)
     static constexpr bool kSplitLevels = WAVES == 8 && !TFA_PBS8_BOTH;
-    static constexpr int kChunkRows = kSplitLevels ? TFA_RING8_ROWS : 16;  // 1 KiB key rows per chunk
+    static constexpr int kChunkRows = WAVES == 8 ? TFA_RING8_ROWS : 16;  // 1 KiB key rows per chunk
     static constexpr int kChunkBytes = kChunkRows * 1024;
     static constexpr int kChunksPerStep = 128 / kChunkRows;
     static constexpr int kSlots = WAVES == 8 ? 64 / kChunkRows : 5;
@@ -175,6 +175,9 @@ __device__ __forceinline__ void transpose16_plane(double (&v)[16], double *tr, i
     for (int r = 0; r < 16; r++) v[r] = base[t * kTrRow + r];
 }
 __device__ __forceinline__ void transpose16(double (&re)[16], double (&im)[16], double *tr, int g, int t) {
+#ifdef TFA_EXP_NOTRANSPOSE  // timing experiment: no exchange between the two DFT16 (results are garbage)
+    return;
+#endif
     transpose16_plane(re, tr, g, t);
     transpose16_plane(im, tr, g, t);
 }
@@ -346,7 +349,7 @@ __device__ __forceinline__ size_t chunk_row_index(uint32_t chunk, int row) {
         constexpr int kPerLevel = G::kChunksPerStep / 2, kGroups = G::kChunkRows / 4;  // chunks per level, frequency groups per chunk
         return bsk_index(i, q / kPerLevel, kGroups * (q % kPerLevel) + (row >> 2), row & 3);
     } else {
-        return bsk_index(i, (row >> 2) & 1, 2 * q + (row >> 3), row & 3);
+        return bsk_index(i, (row >> 2) & 1, (G::kChunkRows / 8) * q + (row >> 3), row & 3);
     }
 }
 // LDS-DMA of chunk `chunk` (global index over all steps) into its ring slot, 16 / WAVES rows per wave.
@@ -540,12 +543,16 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
                 TFA_RING_ACQUIRE(slot, i * G::kChunksPerStep + q)
                 TFA_STAMP(4);
 #pragma unroll
-                for (int kk = 0; kk < 2; kk++) {
-                    const int k2 = 2 * q + kk;
+                for (int kk = 0; kk < G::kChunkRows / 8; kk++) {
+                    const int k2 = (G::kChunkRows / 8) * q + kk;
                     double pr[4], pi[4];
 #pragma unroll
                     for (int c = 0; c < 4; c++) {
+#ifdef TFA_EXP_NOKEYREAD  // timing experiment: key words from registers (results are garbage)
+                        const c64 b0 = c64{f1r[(k2 + c + 1) & 15], f2i[(k2 + c + 2) & 15]}, b1 = c64{f2r[(k2 + c + 3) & 15], f1i[(k2 + c + 4) & 15]};
+#else
                         const c64 b0 = slot[((kk * 2 + 0) * 4 + c) * 64], b1 = slot[((kk * 2 + 1) * 4 + c) * 64];
+#endif
                         pr[c] = f1r[k2] * b0.x - f1i[k2] * b0.y + f2r[k2] * b1.x - f2i[k2] * b1.y;
                         pi[c] = f1r[k2] * b0.y + f1i[k2] * b0.x + f2r[k2] * b1.y + f2i[k2] * b1.x;
                     }
