@@ -363,7 +363,10 @@ __device__ __forceinline__ void ring_issue(const c64 *bsk_f, uint32_t chunk, uns
 #pragma unroll
     for (int j = 0; j < G::kRowsPerWave; j++) {
         const int row = wave * G::kRowsPerWave + j;
-        auto gsrc = (const __attribute__((address_space(1))) void *)(reinterpret_cast<uintptr_t>(bsk_f + chunk_row_index<WAVES>(chunk, row) + lane));
+        // wave-uniform row pointer plus a 32-bit lane offset: lets the load use its scalar-base form instead of a
+        // 64-bit per-lane address that would have to stay in (or be reloaded into) a register pair
+        const char *row_ptr = reinterpret_cast<const char *>(bsk_f + chunk_row_index<WAVES>(chunk, row));
+        auto gsrc = (const __attribute__((address_space(1))) void *)(reinterpret_cast<uintptr_t>(row_ptr + (uint32_t)(lane * 16)));
         auto ldst = (__attribute__((address_space(3))) void *)(reinterpret_cast<uintptr_t>(dst + row * 1024));
         __builtin_amdgcn_global_load_lds(gsrc, ldst, 16, 0, 0);
     }
@@ -467,6 +470,16 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (uint32_t ch = 0; ch < G::kSlots - 1 && ch < n_chunks; ch++) ring_issue<WAVES>(bsk_f, ch, ring, wave, lane);
 
+#ifdef TFA_EXP_SKEW  // timing experiment (with NODMA + NOBARRIER): the second wave of every SIMD starts about half a step late
+    if (WAVES == 8 && wave >= 4) {
+        double xr[16], xi[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) xr[q] = (double)acc[q], xi[q] = (double)acc[q + 16];
+        for (int rep = 0; rep < TFA_EXP_SKEW; rep++) fft_forward(xr, xi, twl, tr, g, t);
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc[q] += round_torus(xr[q]) + round_torus(xi[q]);
+    }
+#endif
     TFA_STAMP_DECL
     for (uint32_t i = 0; i < n_steps; i++) {
         TFA_STAMP(0);
