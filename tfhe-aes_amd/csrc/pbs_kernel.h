@@ -15,6 +15,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
+#include <utility>
 
 namespace tfa {
 
@@ -52,6 +54,17 @@ constexpr int kTwBytes = 4096;                   // per-lane twiddle table share
 #endif
 #ifndef TFA_PBS8_BOTH
 #define TFA_PBS8_BOTH 1  // 0 builds the older 8-wave variant that reduces each level on its own (15 % slower)
+#endif
+#ifdef TFA_NO_SCHED_FENCE
+#define TFA_SCHED_FENCE() ((void)0)
+#else
+#define TFA_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+#ifndef TFA_PIN_SPECTRA
+#define TFA_PIN_SPECTRA 1
+#endif
+#ifndef TFA_PBS8_PREFETCH
+#define TFA_PBS8_PREFETCH 1  // 8 waves: key words of the next frequency group are read while the previous group is reduced
 #endif
 template <int WAVES>
 struct PbsGeom {
@@ -305,6 +318,37 @@ __device__ __forceinline__ double reduce_scatter_rows(double p0, double p1, doub
     return sa + sb;
 }
 
+// ---- pinned LDS reads of key words ------------------------------------------------------------
+typedef double v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t lds_offset(const void *p) { return (uint32_t)reinterpret_cast<uintptr_t>(p); }  // low half of a flat LDS address
+// Reads the 16-byte key word BYTES past this lane's slot address.  dep0 / dep1 are not used by the instruction: they
+// make it wait, in program order, for the values whose computation released the destination registers.  The compiler
+// does not count these reads: key_wait() must come before the first use of their results.
+template <int BYTES>
+__device__ __forceinline__ v2d key_read_at(uint32_t addr, double dep0, double dep1) {
+    v2d v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(BYTES), "v"(dep0), "v"(dep1));
+    return v;
+}
+__device__ __forceinline__ void key_wait(v2d &a, v2d &b, v2d &c, v2d &d, v2d &e, v2d &f, v2d &g, v2d &h) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+}
+// Forces the 16 values to exist in registers at this point of the program (an empty instruction that "modifies" them):
+// keeps the compiler from evaluating the tail of a transform lazily inside the code that follows, which stretches the
+// live ranges of the transform's inputs over that code.
+__device__ __forceinline__ void pin16(double (&a)[16]) {
+    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+    asm volatile("" : "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]));
+}
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 // ---- integer helpers -------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t modswitch_2n(uint32_t x) {  // closest multiple of q/1024, index mod 1024
     return (((x >> 21) + 1u) >> 1) & 1023u;
@@ -335,8 +379,15 @@ __device__ __forceinline__ uint32_t round_torus(double x) {
     return __builtin_bit_cast(uint2, x).x;
 }
 
-// bsk_f layout (c64): [i][level][k2][c][row g][t]: one (level, k2, c) row is 1 KiB = the 64 lanes of a wave.
-__device__ __forceinline__ size_t bsk_index(uint32_t i, int lv, int k2, int c) { return ((((size_t)i * kLevels + lv) * 16 + k2) * kK1 + c) * 64; }
+// bsk_f layout (c64): [i][level][p][c][row g][t]: one (level, p, c) row is 1 KiB = the 64 lanes of a wave.  Position p
+// holds frequency group k2 = kperm(p) = 0, 4, 8, 12, 1, 5, ...: the order in which the last radix-4 layer of the forward
+// transform produces the groups and the first layer of the inverse transform consumes them, so the products stream
+// from one transform into the other without the whole spectrum being live.
+#ifndef TFA_K2_PERM
+#define TFA_K2_PERM 1
+#endif
+__host__ __device__ constexpr int kperm(int p) { return TFA_K2_PERM ? 4 * (p & 3) + (p >> 2) : p; }  // an involution
+__device__ __forceinline__ size_t bsk_index(uint32_t i, int lv, int p, int c) { return ((((size_t)i * kLevels + lv) * 16 + p) * kK1 + c) * 64; }
 
 // Ring chunks.  A chunk is 16 key rows of 1 KiB.  With 4 waves a chunk holds both levels of two
 // frequency groups (the two levels are multiplied and reduced together); with 8 waves it holds one
@@ -532,7 +583,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
                     TFA_STAMP(4);  // ring wait + barrier + refill issue
 #pragma unroll
                     for (int kq = 0; kq < kGroups; kq++) {
-                        const int k2 = kGroups * qq + kq;
+                        const int k2 = kperm(kGroups * qq + kq);
                         double pr[4], pi[4];
 #pragma unroll
                         for (int c = 0; c < 4; c++) {
@@ -546,6 +597,48 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
                     TFA_STAMP(5);  // key products + row reduction of one chunk
                 }
             }
+        } else if constexpr (WAVES == 8 && TFA_PBS8_PREFETCH) {
+            // Both levels transformed one after the other.  Key words are read from the ring one frequency group ahead,
+            // each pair of words (column c, both levels) into the registers that the products of column c have just
+            // released, so the reads travel behind the remaining products and the row reduction and cost no extra
+            // registers.  The reads are inline asm pinned after those products by (unused) operands; the compiler does
+            // not count them, so every group starts with an explicit wait.
+            fft_forward(f1r, f1i, twl, tr, g, t);
+            fft_forward(f2r, f2i, twl, tr, g, t);
+#if TFA_PIN_SPECTRA
+            pin16(f1r), pin16(f1i), pin16(f2r), pin16(f2i);
+#endif
+            TFA_STAMP(3);
+            constexpr int kPerChunk = G::kChunkRows / 8;  // frequency groups per chunk
+            v2d kb[8];                                    // [level * 4 + column]
+            uint32_t kaddr;
+            {
+                TFA_RING_ACQUIRE(slot, i * G::kChunksPerStep)
+                kaddr = lds_offset(slot);
+                static_for<8>([&](auto R) __attribute__((always_inline)) { kb[R.value] = key_read_at<R.value * 1024>(kaddr, 0.0, 0.0); });
+            }
+            static_for<16>([&](auto POS) __attribute__((always_inline)) {
+                constexpr int pos = POS.value, k2 = kperm(pos), kk = (pos + 1) % kPerChunk;
+                key_wait(kb[0], kb[1], kb[2], kb[3], kb[4], kb[5], kb[6], kb[7]);
+                if constexpr (pos + 1 < 16 && kk == 0) {  // next group opens the next chunk; this wave holds all it needs of the current one
+                    TFA_RING_ACQUIRE(slot, i * G::kChunksPerStep + (pos + 1) / kPerChunk)
+                    kaddr = lds_offset(slot);
+                }
+                double pr[4], pi[4];
+                static_for<4>([&](auto C) __attribute__((always_inline)) {
+                    constexpr int c = C.value;
+                    const v2d b0 = kb[c], b1 = kb[4 + c];
+                    pr[c] = f1r[k2] * b0.x - f1i[k2] * b0.y + f2r[k2] * b1.x - f2i[k2] * b1.y;
+                    pi[c] = f1r[k2] * b0.y + f1i[k2] * b0.x + f2r[k2] * b1.y + f2i[k2] * b1.x;
+                    if constexpr (pos + 1 < 16) {
+                        kb[c] = key_read_at<(kk * 8 + c) * 1024>(kaddr, pr[c], pi[c]);
+                        kb[4 + c] = key_read_at<(kk * 8 + 4 + c) * 1024>(kaddr, pr[c], pi[c]);
+                    }
+                });
+                our[k2] = reduce_scatter_rows(pr[0], pr[1], pr[2], pr[3]);
+                oui[k2] = reduce_scatter_rows(pi[0], pi[1], pi[2], pi[3]);
+            });
+            TFA_STAMP(5);
         } else if constexpr (WAVES == 8) {
             // both levels transformed one after the other, key words read from the ring as they are used
             fft_forward(f1r, f1i, twl, tr, g, t);
@@ -557,7 +650,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
                 TFA_STAMP(4);
 #pragma unroll
                 for (int kk = 0; kk < G::kChunkRows / 8; kk++) {
-                    const int k2 = (G::kChunkRows / 8) * q + kk;
+                    const int k2 = kperm((G::kChunkRows / 8) * q + kk);
                     double pr[4], pi[4];
 #pragma unroll
                     for (int c = 0; c < 4; c++) {
@@ -595,7 +688,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
                 TFA_STAMP(4);
 #pragma unroll
                 for (int kk = 0; kk < 2; kk++) {
-                    const int k2 = 2 * q + kk;
+                    const int k2 = kperm(2 * q + kk);
                     double pr[4], pi[4];
 #pragma unroll
                     for (int c = 0; c < 4; c++) {
@@ -660,7 +753,7 @@ __global__ void __launch_bounds__(256, 1)
     fft_forward(re, im, tw, tr, g, t);
     const uint32_t r = row & 3, lv = (row >> 2) % kLevels, i = (row >> 2) / kLevels;
 #pragma unroll
-    for (int k2 = 0; k2 < 16; k2++) bsk_f[bsk_index(i, lv, k2, g) + r * 16 + t] = c64{re[k2] * (1.0 / 256.0), im[k2] * (1.0 / 256.0)};
+    for (int k2 = 0; k2 < 16; k2++) bsk_f[bsk_index(i, lv, kperm(k2), g) + r * 16 + t] = c64{re[k2] * (1.0 / 256.0), im[k2] * (1.0 / 256.0)};
 }
 
 }  // namespace tfa
