@@ -60,6 +60,12 @@ constexpr int kTwBytes = 4096;                   // per-lane twiddle table share
 #else
 #define TFA_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
+#ifndef TFA_INV_TW_PREFETCH
+#define TFA_INV_TW_PREFETCH 0  // 8 waves: 1 = the inverse transform's twiddles are read before its first DFT16 (measured 4 % slower)
+#endif
+#ifndef TFA_FFT_PAIR
+#define TFA_FFT_PAIR 0  // 8 waves: 1 = the two forward transforms of a step share their twiddle reads (fewer LDS reads, measured 2.5 % slower)
+#endif
 #ifndef TFA_PIN_SPECTRA
 #define TFA_PIN_SPECTRA 1
 #endif
@@ -181,11 +187,15 @@ __device__ constexpr double kS32[16] = {0.0, 0.0980171403295606, 0.1950903220161
 __device__ __forceinline__ void transpose16_plane(double (&v)[16], double *tr, int g, int t) {
     double *base = tr + g * kTrGroup;
     wave_lds_fence();  // earlier reads of the aliased buffer are done
+#ifndef TFA_EXP_TR_NOWRITE  // timing experiments: one direction of the exchange only (results are garbage)
 #pragma unroll
     for (int r = 0; r < 16; r++) base[r * kTrRow + t] = v[r];
+#endif
     wave_lds_fence();
+#ifndef TFA_EXP_TR_NOREAD
 #pragma unroll
     for (int r = 0; r < 16; r++) v[r] = base[t * kTrRow + r];
+#endif
 }
 __device__ __forceinline__ void transpose16(double (&re)[16], double (&im)[16], double *tr, int g, int t) {
 #ifdef TFA_EXP_NOTRANSPOSE  // timing experiment: no exchange between the two DFT16 (results are garbage)
@@ -224,6 +234,28 @@ __device__ __forceinline__ void fft_inverse(double (&re)[16], double (&im)[16], 
     for (int n1 = 1; n1 < 16; n1++) cmulc<-1>(re[n1], im[n1], kC32[n1], kS32[n1]);
 }
 
+// Two forward transforms on one transpose buffer: every twiddle is read once for both, and the two independent
+// dependency chains interleave.  Used by the two-waves-per-SIMD variant.
+__device__ __forceinline__ void fft_forward_pair(double (&ar)[16], double (&ai)[16], double (&br)[16], double (&bi)[16], const c64 *twl, double *tr,
+                                                 int g, int t) {
+#pragma unroll
+    for (int n1 = 1; n1 < 16; n1++) {
+        cmulc<1>(ar[n1], ai[n1], kC32[n1], kS32[n1]);
+        cmulc<1>(br[n1], bi[n1], kC32[n1], kS32[n1]);
+    }
+    dft16<1>(ar, ai);
+    dft16<1>(br, bi);
+#pragma unroll
+    for (int k1 = 0; k1 < 16; k1++) {
+        c64 w = twl[k1 * 16 + t];
+        cmulc<1>(ar[k1], ai[k1], w.x, w.y);
+        cmulc<1>(br[k1], bi[k1], w.x, w.y);
+    }
+    transpose16(ar, ai, tr, g, t);
+    transpose16(br, bi, tr, g, t);
+    dft16<1>(ar, ai);
+    dft16<1>(br, bi);
+}
 // Two independent forward transforms interleaved (two transpose buffers): the LDS round trips of one
 // overlap the arithmetic of the other.  Used by the one-wave-per-SIMD variant.
 __device__ __forceinline__ void fft_forward2(double (&ar)[16], double (&ai)[16], double (&br)[16], double (&bi)[16], const c64 *twl, double *trA,
@@ -326,9 +358,13 @@ __device__ __forceinline__ uint32_t lds_offset(const void *p) { return (uint32_t
 // does not count these reads: key_wait() must come before the first use of their results.
 template <int BYTES>
 __device__ __forceinline__ v2d key_read_at(uint32_t addr, double dep0, double dep1) {
+#ifdef TFA_EXP_NOKEYREAD  // timing experiment: no LDS read (results are garbage)
+    return v2d{dep0 + 1.0, dep1 - 1.0};
+#else
     v2d v;
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(BYTES), "v"(dep0), "v"(dep1));
     return v;
+#endif
 }
 __device__ __forceinline__ void key_wait(v2d &a, v2d &b, v2d &c, v2d &d, v2d &e, v2d &f, v2d &g, v2d &h) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
@@ -347,6 +383,23 @@ __device__ __forceinline__ void static_for_impl(F &f, std::integer_sequence<int,
 template <int N, class F>
 __device__ __forceinline__ void static_for(F &&f) {
     static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// Inverse transform whose sixteen twiddles are read (pinned, uncounted by the compiler) before the first register
+// DFT16, behind the values dep0 / dep1, and so arrive long before the twiddle products need them.
+__device__ __forceinline__ void fft_inverse_pf(double (&re)[16], double (&im)[16], const c64 *twl, double *tr, int g, int t) {
+    v2d w[16];
+    const uint32_t waddr = lds_offset(twl + t);
+    static_for<16>([&](auto K) __attribute__((always_inline)) { w[K.value] = key_read_at<K.value * 256>(waddr, re[15], im[15]); });
+    dft16<-1>(re, im);
+    transpose16(re, im, tr, g, t);
+    key_wait(w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]);
+    key_wait(w[8], w[9], w[10], w[11], w[12], w[13], w[14], w[15]);
+#pragma unroll
+    for (int k1 = 0; k1 < 16; k1++) cmulc<-1>(re[k1], im[k1], w[k1].x, w[k1].y);
+    dft16<-1>(re, im);
+#pragma unroll
+    for (int n1 = 1; n1 < 16; n1++) cmulc<-1>(re[n1], im[n1], kC32[n1], kS32[n1]);
 }
 
 // ---- integer helpers -------------------------------------------------------------------------
@@ -603,8 +656,12 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
             // released, so the reads travel behind the remaining products and the row reduction and cost no extra
             // registers.  The reads are inline asm pinned after those products by (unused) operands; the compiler does
             // not count them, so every group starts with an explicit wait.
+#if TFA_FFT_PAIR
+            fft_forward_pair(f1r, f1i, f2r, f2i, twl, tr, g, t);
+#else
             fft_forward(f1r, f1i, twl, tr, g, t);
             fft_forward(f2r, f2i, twl, tr, g, t);
+#endif
 #if TFA_PIN_SPECTRA
             pin16(f1r), pin16(f1i), pin16(f2r), pin16(f2i);
 #endif
@@ -624,6 +681,8 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
                     TFA_RING_ACQUIRE(slot, i * G::kChunksPerStep + (pos + 1) / kPerChunk)
                     kaddr = lds_offset(slot);
                 }
+                // (Measured and rejected: products level by level with the first level's registers refilled behind the
+                // second level's products and separate waits per level: 7 % slower, the shorter chains leave less to interleave.)
                 double pr[4], pi[4];
                 static_for<4>([&](auto C) __attribute__((always_inline)) {
                     constexpr int c = C.value;
@@ -643,6 +702,9 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
             // both levels transformed one after the other, key words read from the ring as they are used
             fft_forward(f1r, f1i, twl, tr, g, t);
             fft_forward(f2r, f2i, twl, tr, g, t);
+#if TFA_PIN_SPECTRA
+            pin16(f1r), pin16(f1i), pin16(f2r), pin16(f2i);
+#endif
             TFA_STAMP(3);
 #pragma unroll
             for (int q = 0; q < G::kChunksPerStep; q++) {
@@ -669,6 +731,9 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
             }
         } else {
             fft_forward2(f1r, f1i, f2r, f2i, twl, tr, tr2, g, t);
+#if TFA_PIN_SPECTRA
+            pin16(f1r), pin16(f1i), pin16(f2r), pin16(f2i);
+#endif
             TFA_STAMP(3);
             // key words of a chunk are read into registers one barrier ahead of their use, so the LDS read
             // latency and the barrier hide behind the products of the previous chunk
@@ -704,8 +769,10 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
         }
         if constexpr (WAVES == 4)
             fft_inverse2buf(our, oui, twl, tr, tr2, g, t);
+        else if constexpr (TFA_INV_TW_PREFETCH && !G::kSplitLevels)
+            fft_inverse_pf(our, oui, twl, tr, g, t);
         else
-        fft_inverse(our, oui, twl, tr, g, t);
+            fft_inverse(our, oui, twl, tr, g, t);
         TFA_STAMP(6);  // inverse transform
 #pragma unroll
         for (int q = 0; q < 16; q++) {
