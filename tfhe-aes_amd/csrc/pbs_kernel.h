@@ -63,6 +63,9 @@ constexpr int kTwBytes = 4096;                   // per-lane twiddle table share
 #ifndef TFA_INV_TW_PREFETCH
 #define TFA_INV_TW_PREFETCH 0  // 8 waves: 1 = the inverse transform's twiddles are read before its first DFT16 (measured 4 % slower)
 #endif
+#ifndef TFA_TR_FENCES
+#define TFA_TR_FENCES 1  // 1 = compiler fences around every plane of a transpose; 0 = one fence per transpose (the planes' accesses may alias, which orders them)
+#endif
 #ifndef TFA_FFT_PAIR
 #define TFA_FFT_PAIR 0  // 8 waves: 1 = the two forward transforms of a step share their twiddle reads (fewer LDS reads, measured 2.5 % slower)
 #endif
@@ -186,12 +189,23 @@ __device__ constexpr double kS32[16] = {0.0, 0.0980171403295606, 0.1950903220161
 // plane at a time: lane t writes element r to [g][r][t] and reads back [g][t][r].
 __device__ __forceinline__ void transpose16_plane(double (&v)[16], double *tr, int g, int t) {
     double *base = tr + g * kTrGroup;
+#if TFA_TR_FENCES
     wave_lds_fence();  // earlier reads of the aliased buffer are done
+#endif
 #ifndef TFA_EXP_TR_NOWRITE  // timing experiments: one direction of the exchange only (results are garbage)
 #pragma unroll
     for (int r = 0; r < 16; r++) base[r * kTrRow + t] = v[r];
+#else
+    {  // keeps the values alive at the price of integer operations and a single store
+        uint32_t x = 0;
+#pragma unroll
+        for (int r = 0; r < 16; r++) x ^= __builtin_bit_cast(uint2, v[r]).x ^ __builtin_bit_cast(uint2, v[r]).y;
+        reinterpret_cast<uint32_t *>(base)[t] = x;
+    }
 #endif
+#if TFA_TR_FENCES
     wave_lds_fence();
+#endif
 #ifndef TFA_EXP_TR_NOREAD
 #pragma unroll
     for (int r = 0; r < 16; r++) v[r] = base[t * kTrRow + r];
@@ -200,6 +214,9 @@ __device__ __forceinline__ void transpose16_plane(double (&v)[16], double *tr, i
 __device__ __forceinline__ void transpose16(double (&re)[16], double (&im)[16], double *tr, int g, int t) {
 #ifdef TFA_EXP_NOTRANSPOSE  // timing experiment: no exchange between the two DFT16 (results are garbage)
     return;
+#endif
+#if !TFA_TR_FENCES
+    wave_lds_fence();  // orders the exchange after earlier accesses to the aliased rotation buffer (other element type)
 #endif
     transpose16_plane(re, tr, g, t);
     transpose16_plane(im, tr, g, t);

@@ -19,6 +19,10 @@
 
 namespace tfa {
 
+#ifndef TFA_LAT_TOUCH
+#define TFA_LAT_TOUCH 1
+#endif
+constexpr uint32_t kLatTouchAhead = 3;                  // steps between the L2 warm-up of a step's key and its use
 constexpr int kLatFftElems = 320;                       // 256 points, one c64 of padding after every 4
 constexpr int kLatFftBytes = kLatFftElems * 16;         // 5120
 constexpr int kLatWaveBytes = 2 * kLatFftBytes;         // one transform buffer per level; the first doubles as rotation buffer
@@ -72,6 +76,9 @@ __device__ __forceinline__ int lat_pos(int s, int L, int slot) {
 // hand-over between stage `s_from` (results written to its positions) and stage `s_to` (operands read from its positions)
 template <int NL>
 __device__ __forceinline__ void lat_exchange(double (&zr)[NL][4], double (&zi)[NL][4], c64 *fb, int s_from, int s_to, int L) {
+#ifdef TFA_EXP_LAT_NOEXCH  // timing experiment: no hand-over between stages (results are garbage)
+    return;
+#endif
 #pragma unroll
     for (int lv = 0; lv < NL; lv++)
 #pragma unroll
@@ -95,6 +102,9 @@ __device__ __forceinline__ void lat_stage(double (&zr)[NL][4], double (&zi)[NL][
     if (s == 3) return;
 #pragma unroll
     for (int r = 0; r < 3; r++) cmulc<1>(zr[lv][r + 1], zi[lv][r + 1], T.sr[s][r], T.si[s][r]);
+#ifdef TFA_EXP_LAT_NOEXCH
+    return;
+#endif
 #pragma unroll
     for (int r = 0; r < 4; r++) fb[lv * kLatFftElems + lat_pos(s, L, r)] = c64{zr[lv][r], zi[lv][r]};
     wave_lds_fence();
@@ -187,8 +197,19 @@ __global__ void __launch_bounds__(256, PER_CU)
                 for (int q = 0; q < 4; q++) key[lv][c][q] = bsk_lat[bsk_lat_index(0, lv, c, w, q) + L];
     }
 
+    // L2 warm-up: every workgroup of an XCD (workgroups go to the XCDs round-robin) touches its share of the 1024
+    // 128-byte lines of the key of step i + kLatTouchAhead, so the key reads one step ahead hit the XCD's L2
+    const uint32_t touch_wgs = (gridDim.x + 7) / 8, touch_line = blockIdx.x / 8 + threadIdx.x * touch_wgs;
+    uint32_t touched = 0;
     for (uint32_t i = 0; i < n_steps; i++) {
         const int a = __builtin_amdgcn_readfirstlane((int)a_tilde[i]);
+#if TFA_LAT_TOUCH
+        {
+            asm volatile("" ::"v"(touched));  // the previous step's touch has returned by now (keeps the load alive and counted)
+            if (touch_line < 1024 && i + kLatTouchAhead < n_steps)
+                touched = reinterpret_cast<const volatile uint32_t *>(bsk_lat + (size_t)(i + kLatTouchAhead) * 8192)[touch_line * 32];
+        }
+#endif
         // d = acc * X^a - acc through the rotation buffer, then signed decomposition
         wave_lds_fence();
 #pragma unroll
@@ -238,13 +259,19 @@ __global__ void __launch_bounds__(256, PER_CU)
                     oui[0][q] += zr[lv][q] * b.y + zi[lv][q] * b.x;
                 }
         }
+#ifndef TFA_EXP_NOBARRIER
         __syncthreads();
+#endif
 #pragma unroll
         for (int p = 0; p < 4; p++) {
             if (p == w) continue;
             c64 f[8];  // all eight reads of a polynomial in flight before the first product
 #pragma unroll
+#ifdef TFA_EXP_LAT_NOSPEC  // timing experiment: other polynomials' spectra from registers (results are garbage)
+            for (int e = 0; e < 8; e++) f[e] = c64{zr[e >> 2][e & 3] + p, zi[e >> 2][e & 3] - p};
+#else
             for (int e = 0; e < 8; e++) f[e] = sp[(p * 8 + e) * 64 + L];
+#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int lv = 0; lv < 2; lv++)
@@ -255,7 +282,9 @@ __global__ void __launch_bounds__(256, PER_CU)
                     oui[0][q] += f[lv * 4 + q].x * b.y + f[lv * 4 + q].y * b.x;
                 }
         }
+#ifndef TFA_EXP_NOBARRIER
         if (LatGeom<PER_CU>::kSpecBuffers == 1) __syncthreads();
+#endif
         // next step's key words replace the ones just consumed; they have almost a whole step to arrive
 #ifdef TFA_EXP_NODMA  // timing experiment: the first step's key words are reused (results are garbage)
         if (false) {
