@@ -385,13 +385,13 @@ static int launch_pbs(tfa_ctx *ctx, const uint32_t *in_base, uint32_t in_stride,
     // workgroups over all CUs, microseconds, MI355X):
     //   8 bootstraps per workgroup, two waves per SIMD (highest throughput)          12500 per 8 * CUs
     //   4 bootstraps per workgroup, one wave per SIMD                                  8400 per 4 * CUs
-    //   one bootstrap spread over the 4 waves of a workgroup, one workgroup per CU    3450 per CUs
-    //   the same with two workgroups per CU                                           5400 per 2 * CUs
+    //   one bootstrap spread over the 4 waves of a workgroup, one workgroup per CU    3100 per CUs
+    //   the same with two workgroups per CU                                           5200 per 2 * CUs
     // A batch that fills whole rounds of the 8-wave kernel and leaves a short tail runs the tail separately.
     const uint64_t cus = ctx->n_cus;
     auto best_single = [&](uint64_t P, int &variant) -> uint64_t {
         const uint64_t t8 = ((P + 8 * cus - 1) / (8 * cus)) * 12500, t4 = ((P + 4 * cus - 1) / (4 * cus)) * 8400;
-        const uint64_t lat_rest = P % (2 * cus), t_lat = (P / (2 * cus)) * 5400 + (lat_rest == 0 ? 0 : lat_rest <= cus ? 3450 : 5400);
+        const uint64_t lat_rest = P % (2 * cus), t_lat = (P / (2 * cus)) * 5200 + (lat_rest == 0 ? 0 : lat_rest <= cus ? 3100 : 5200);
         variant = t_lat <= t4 && t_lat <= t8 ? (P > cus ? 2 : 1) : (t8 < t4 ? 8 : 4);
         return variant == 8 ? t8 : variant == 4 ? t4 : t_lat;
     };

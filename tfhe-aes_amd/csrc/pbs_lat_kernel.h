@@ -19,6 +19,9 @@
 
 namespace tfa {
 
+#ifndef TFA_LAT_SPREAD_KEY
+#define TFA_LAT_SPREAD_KEY 1
+#endif
 #ifndef TFA_LAT_TOUCH
 #define TFA_LAT_TOUCH 1
 #endif
@@ -130,10 +133,14 @@ __device__ __forceinline__ void lat_forward(double (&zr)[NL][4], double (&zi)[NL
         for (int lv = 0; lv < NL; lv++) lat_stage<NL>(zr, zi, lv, s, T, fb, L);
 }
 
-// exact mirror of lat_forward (times 256)
-__device__ __forceinline__ void lat_inverse(double (&zr)[1][4], double (&zi)[1][4], const LatTwiddles &T, c64 *fb, int L) {
+// exact mirror of lat_forward (times 256).  between(s) runs before stage s: independent work (the next step's key
+// reads) that the compiler may not move across the hand-overs' fences by itself, placed where the wave would
+// otherwise only wait for the LDS.
+template <class Between>
+__device__ __forceinline__ void lat_inverse(double (&zr)[1][4], double (&zi)[1][4], const LatTwiddles &T, c64 *fb, int L, Between &&between) {
 #pragma unroll
     for (int s = 3; s >= 0; s--) {
+        between(s);
         if (s < 3) {
 #pragma unroll
             for (int r = 0; r < 3; r++) cmulc<-1>(zr[0][r + 1], zi[0][r + 1], T.sr[s][r], T.si[s][r]);
@@ -287,10 +294,22 @@ __global__ void __launch_bounds__(256, PER_CU)
 #endif
         // next step's key words replace the ones just consumed; they have almost a whole step to arrive
 #ifdef TFA_EXP_NODMA  // timing experiment: the first step's key words are reused (results are garbage)
-        if (false) {
+        const bool more = false;
 #else
-        if (i + 1 < n_steps) {
+        const bool more = i + 1 < n_steps;
 #endif
+#if TFA_LAT_SPREAD_KEY
+        // a quarter of the next step's key words before each stage of the inverse transform
+        lat_inverse(our, oui, T, fb, L, [&](int s) __attribute__((always_inline)) {
+            if (more) {
+#pragma unroll
+                for (int lv = 0; lv < 2; lv++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) key[lv][3 - s][q] = bsk_lat[bsk_lat_index(i + 1, lv, 3 - s, w, q) + L];
+            }
+        });
+#else
+        if (more) {
 #pragma unroll
             for (int lv = 0; lv < 2; lv++)
 #pragma unroll
@@ -298,7 +317,8 @@ __global__ void __launch_bounds__(256, PER_CU)
 #pragma unroll
                     for (int q = 0; q < 4; q++) key[lv][p][q] = bsk_lat[bsk_lat_index(i + 1, lv, p, w, q) + L];
         }
-        lat_inverse(our, oui, T, fb, L);
+        lat_inverse(our, oui, T, fb, L, [](int) {});
+#endif
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             acc[q] += round_torus(our[0][q]);
