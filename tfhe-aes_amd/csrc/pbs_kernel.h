@@ -601,6 +601,9 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
         for (int q = 0; q < 16; q++) acc[q] += round_torus(xr[q]) + round_torus(xi[q]);
     }
 #endif
+#ifdef TFA_EXP_PRIO  // timing experiment: the second wave of every SIMD issues with priority
+    if (WAVES == 8 && wave >= 4) __builtin_amdgcn_s_setprio(TFA_EXP_PRIO);
+#endif
     TFA_STAMP_DECL
     for (uint32_t i = 0; i < n_steps; i++) {
         TFA_STAMP(0);
