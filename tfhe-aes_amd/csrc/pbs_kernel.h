@@ -41,9 +41,15 @@ constexpr int kK1 = 4;           // glwe_dimension + 1
 constexpr int kLevels = 2;       // pbs_level
 constexpr int kBaseLog = 10;     // pbs_base_log
 constexpr int kRotStride = 528;  // u32 words per polynomial in the rotation buffer (528 % 32 == 16)
-constexpr int kTrRow = 17;       // doubles per padded transpose row
+#ifndef TFA_TR_ROW
+#define TFA_TR_ROW 18
+#endif
+// doubles per padded transpose row: 18 keeps every row 16-byte aligned, so a lane reads its row with eight conflict-free
+// ds_read_b128 (lane t starts at dword 36 t mod 64: the sixteen lanes of a group cover the 64 banks exactly once);
+// 17 (8-byte reads in pairs, twice the LDS cycles) measured 2 % slower
+constexpr int kTrRow = TFA_TR_ROW;
 constexpr int kTrGroup = 16 * kTrRow;
-constexpr int kWaveLdsBytes = 4 * kTrGroup * 8;  // 8704: transpose buffer (one real plane at a time), aliased by the rotation buffer
+constexpr int kWaveLdsBytes = 4 * kTrGroup * 8;  // 9216: transpose buffer (one real plane at a time), aliased by the rotation buffer
 constexpr int kABytes = 1664;                    // modulus-switched mask, u16[<=832]
 constexpr int kWavePrivBytes = kWaveLdsBytes + kABytes;
 constexpr int kTwBytes = 4096;                   // per-lane twiddle table shared by all waves
@@ -83,7 +89,7 @@ struct PbsGeom {
     static constexpr int kChunkRows = WAVES == 8 ? TFA_RING8_ROWS : 16;  // 1 KiB key rows per chunk
     static constexpr int kChunkBytes = kChunkRows * 1024;
     static constexpr int kChunksPerStep = 128 / kChunkRows;
-    static constexpr int kSlots = WAVES == 8 ? 64 / kChunkRows : 5;
+    static constexpr int kSlots = WAVES == 8 ? 64 / kChunkRows : (kTrRow == 17 ? 5 : 4);
     static constexpr int kRowsPerWave = kChunkRows / WAVES;  // DMA rows each wave issues per chunk
     // one wave per SIMD (WAVES == 4) has no partner wave to hide its LDS round trips, so it gets a second
     // transpose buffer and overlaps two transposes with each other and with arithmetic
@@ -207,8 +213,18 @@ __device__ __forceinline__ void transpose16_plane(double (&v)[16], double *tr, i
     wave_lds_fence();
 #endif
 #ifndef TFA_EXP_TR_NOREAD
+    if constexpr (kTrRow % 2 == 0) {  // rows are 16-byte aligned: eight 16-byte reads
+        typedef double v2d_ __attribute__((ext_vector_type(2)));
 #pragma unroll
-    for (int r = 0; r < 16; r++) v[r] = base[t * kTrRow + r];
+        for (int r = 0; r < 16; r += 2) {
+            const v2d_ x = *reinterpret_cast<const v2d_ *>(base + t * kTrRow + r);
+            v[r] = x.x;
+            v[r + 1] = x.y;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = base[t * kTrRow + r];
+    }
 #endif
 }
 __device__ __forceinline__ void transpose16(double (&re)[16], double (&im)[16], double *tr, int g, int t) {
