@@ -81,28 +81,34 @@ constexpr int kTwBytes = 4096;                   // per-lane twiddle table share
 #ifndef TFA_PBS8_PREFETCH
 #define TFA_PBS8_PREFETCH 1  // 8 waves: key words of the next frequency group are read while the previous group is reduced
 #endif
-template <int WAVES>
+// WAVES bootstraps per workgroup, PER_CU workgroups per CU.  (8, 1) and (4, 2) put two waves on every SIMD and run the
+// 256-register code path ("dense"); (4, 1) keeps one wave per SIMD and spends up to 512 registers on prefetching.
+// (4, 2) - two independent workgroups per CU, each with its own 32 KiB ring and a barrier over four waves only - was
+// measured at the same rate as (8, 1) (171 k against 172 k bootstraps/s) and is not instantiated by the engine.
+template <int WAVES, int PER_CU = 1>
 struct PbsGeom {
-    // 8 waves, split mode: each level is transformed, multiplied and reduced on its own; otherwise both levels
+    static constexpr int kWaves = WAVES;
+    static constexpr bool kDense = WAVES * PER_CU == 8;
+    // dense, split mode: each level is transformed, multiplied and reduced on its own; otherwise both levels
     // are transformed first and multiplied and reduced together (half the row reductions)
-    static constexpr bool kSplitLevels = WAVES == 8 && !TFA_PBS8_BOTH;
-    static constexpr int kChunkRows = WAVES == 8 ? TFA_RING8_ROWS : 16;  // 1 KiB key rows per chunk
+    static constexpr bool kSplitLevels = kDense && !TFA_PBS8_BOTH;
+    static constexpr int kChunkRows = kDense ? TFA_RING8_ROWS : 16;  // 1 KiB key rows per chunk
     static constexpr int kChunkBytes = kChunkRows * 1024;
     static constexpr int kChunksPerStep = 128 / kChunkRows;
-    static constexpr int kSlots = WAVES == 8 ? 64 / kChunkRows : (kTrRow == 17 ? 5 : 4);
+    static constexpr int kSlots = kDense ? 64 / (kChunkRows * PER_CU) : (kTrRow == 17 ? 5 : 4);
     static constexpr int kRowsPerWave = kChunkRows / WAVES;  // DMA rows each wave issues per chunk
-    // one wave per SIMD (WAVES == 4) has no partner wave to hide its LDS round trips, so it gets a second
+    // one wave per SIMD has no partner wave to hide its LDS round trips, so it gets a second
     // transpose buffer and overlaps two transposes with each other and with arithmetic
-    static constexpr int kTrBuffers = WAVES == 8 ? 1 : 2;
+    static constexpr int kTrBuffers = kDense ? 1 : 2;
     static constexpr int kWaveBytes = kTrBuffers * kWaveLdsBytes + kABytes;
     static constexpr int kTwOffset = WAVES * kWaveBytes;
     static constexpr int kRingOffset = kTwOffset + kTwBytes;
     static constexpr int kLdsBytes = kRingOffset + kSlots * kChunkBytes;
     static_assert(kSlots >= 2, "ring needs two slots");
+    static_assert(kLdsBytes * PER_CU <= 163840, "LDS budget");
 };
 constexpr int kConvertWaves = 4;
 constexpr int kConvertLdsBytes = kConvertWaves * kWavePrivBytes;
-static_assert(PbsGeom<8>::kLdsBytes <= 163840 && PbsGeom<4>::kLdsBytes <= 163840, "LDS budget");
 static_assert(4 * kRotStride * 4 <= kWaveLdsBytes, "rotation buffer must fit in the transpose buffer");
 
 // One bootstrap: u = ca*in[a] + cb*in[b] + (0,..,0,cst), all wrapping u32.
@@ -478,9 +484,8 @@ __device__ __forceinline__ size_t bsk_index(uint32_t i, int lv, int p, int c) { 
 // Ring chunks.  A chunk is 16 key rows of 1 KiB.  With 4 waves a chunk holds both levels of two
 // frequency groups (the two levels are multiplied and reduced together); with 8 waves it holds one
 // level of four frequency groups (each level is reduced on its own, which halves the live registers).
-template <int WAVES>
+template <class G>
 __device__ __forceinline__ size_t chunk_row_index(uint32_t chunk, int row) {
-    using G = PbsGeom<WAVES>;
     const uint32_t i = chunk / G::kChunksPerStep, q = chunk % G::kChunksPerStep;
     if constexpr (G::kSplitLevels) {
         constexpr int kPerLevel = G::kChunksPerStep / 2, kGroups = G::kChunkRows / 4;  // chunks per level, frequency groups per chunk
@@ -490,9 +495,8 @@ __device__ __forceinline__ size_t chunk_row_index(uint32_t chunk, int row) {
     }
 }
 // LDS-DMA of chunk `chunk` (global index over all steps) into its ring slot, 16 / WAVES rows per wave.
-template <int WAVES>
+template <class G>
 __device__ __forceinline__ void ring_issue(const c64 *bsk_f, uint32_t chunk, unsigned char *ring, int wave, int lane) {
-    using G = PbsGeom<WAVES>;
 #ifdef TFA_EXP_NODMA  // timing experiment: no key traffic at all (results are garbage)
     return;
 #endif
@@ -502,7 +506,7 @@ __device__ __forceinline__ void ring_issue(const c64 *bsk_f, uint32_t chunk, uns
         const int row = wave * G::kRowsPerWave + j;
         // wave-uniform row pointer plus a 32-bit lane offset: lets the load use its scalar-base form instead of a
         // 64-bit per-lane address that would have to stay in (or be reloaded into) a register pair
-        const char *row_ptr = reinterpret_cast<const char *>(bsk_f + chunk_row_index<WAVES>(chunk, row));
+        const char *row_ptr = reinterpret_cast<const char *>(bsk_f + chunk_row_index<G>(chunk, row));
         auto gsrc = (const __attribute__((address_space(1))) void *)(reinterpret_cast<uintptr_t>(row_ptr + (uint32_t)(lane * 16)));
         auto ldst = (__attribute__((address_space(3))) void *)(reinterpret_cast<uintptr_t>(dst + row * 1024));
         __builtin_amdgcn_global_load_lds(gsrc, ldst, 16, 0, 0);
@@ -513,10 +517,9 @@ __device__ __forceinline__ void ring_issue(const c64 *bsk_f, uint32_t chunk, uns
 //                   chunk whose slot is about to be refilled have returned)
 //   s_barrier     : all rows of `ch` are visible and every wave is done with chunk ch-1
 //   ring_refill   : the slot freed by ch-1 is refilled with chunk ch-1+kSlots
-template <int WAVES>
+template <class G>
 __device__ __forceinline__ void ring_wait_own(uint32_t ch, uint32_t n_chunks) {
-    using G = PbsGeom<WAVES>;
-    if constexpr (WAVES == 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (!G::kDense) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // at most the rows of the kSlots-2 younger chunks stay in flight
     if (ch + (G::kSlots - 2) < n_chunks) {
         constexpr int kInFlight = (G::kSlots - 2) * G::kRowsPerWave;
@@ -527,10 +530,9 @@ __device__ __forceinline__ void ring_wait_own(uint32_t ch, uint32_t n_chunks) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 }
-template <int WAVES>
+template <class G>
 __device__ __forceinline__ const c64 *ring_refill(const c64 *bsk_f, uint32_t ch, uint32_t n_chunks, unsigned char *ring, int wave, int lane) {
-    using G = PbsGeom<WAVES>;
-    if (ch + (G::kSlots - 1) < n_chunks) ring_issue<WAVES>(bsk_f, ch + (G::kSlots - 1), ring, wave, lane);
+    if (ch + (G::kSlots - 1) < n_chunks) ring_issue<G>(bsk_f, ch + (G::kSlots - 1), ring, wave, lane);
     return reinterpret_cast<const c64 *>(ring + (ch % G::kSlots) * G::kChunkBytes) + lane;
 }
 #ifdef TFA_EXP_NOBARRIER  // timing experiment: waves run free (results are garbage)
@@ -543,11 +545,11 @@ __device__ __forceinline__ const c64 *ring_refill(const c64 *bsk_f, uint32_t ch,
     {                                                                           \
         const uint32_t ch_ = (ch_expr);                                         \
         TFA_STAMP(8);                                                           \
-        ring_wait_own<WAVES>(ch_, n_chunks);                                    \
+        ring_wait_own<G>(ch_, n_chunks);                                    \
         TFA_STAMP(9);                                                           \
         TFA_RING_BARRIER();                                                     \
         TFA_STAMP(10);                                                          \
-        slot_var = ring_refill<WAVES>(bsk_f, ch_, n_chunks, ring, wave, lane);  \
+        slot_var = ring_refill<G>(bsk_f, ch_, n_chunks, ring, wave, lane);  \
         TFA_STAMP(11);                                                          \
     }
 
@@ -560,12 +562,12 @@ __device__ __forceinline__ const c64 *ring_refill(const c64 *bsk_f, uint32_t ch,
 // Chunk schedule (global chunk index ch = 8*i + q): before consuming ch every wave waits for its own
 // DMA rows of ch, then one barrier makes all rows of ch visible and proves every wave is done with
 // ch-1, whose slot is refilled with ch-1+kSlots right after the barrier.
-template <int WAVES>
-__global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
+template <int WAVES, int PER_CU = 1>
+__global__ void __launch_bounds__(WAVES * 64, WAVES * PER_CU / 4)
     pbs_kernel(const uint32_t *__restrict__ in_base, uint32_t in_stride, const PbsJob *__restrict__ jobs, uint32_t n_jobs,
                const c64 *__restrict__ bsk_f, const c64 *__restrict__ tw, uint32_t n, uint32_t steps, uint32_t *__restrict__ big_out,
                uint32_t big_stride, uint32_t *__restrict__ acc_out) {
-    using G = PbsGeom<WAVES>;
+    using G = PbsGeom<WAVES, PER_CU>;
     extern __shared__ __align__(16) unsigned char lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keep it (and all ring addressing) scalar
     const int lane = threadIdx.x & 63, g = lane >> 4, t = lane & 15;
@@ -605,10 +607,10 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
     // every ordinary load above has been consumed; from here on the only vector-memory operations in
     // flight are the ring's LDS-DMA rows, so vmcnt counts them exactly
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (uint32_t ch = 0; ch < G::kSlots - 1 && ch < n_chunks; ch++) ring_issue<WAVES>(bsk_f, ch, ring, wave, lane);
+    for (uint32_t ch = 0; ch < G::kSlots - 1 && ch < n_chunks; ch++) ring_issue<G>(bsk_f, ch, ring, wave, lane);
 
 #ifdef TFA_EXP_SKEW  // timing experiment (with NODMA + NOBARRIER): the second wave of every SIMD starts about half a step late
-    if (WAVES == 8 && wave >= 4) {
+    if (G::kDense && WAVES == 8 && wave >= 4) {
         double xr[16], xi[16];
 #pragma unroll
         for (int q = 0; q < 16; q++) xr[q] = (double)acc[q], xi[q] = (double)acc[q + 16];
@@ -686,7 +688,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
                     TFA_STAMP(5);  // key products + row reduction of one chunk
                 }
             }
-        } else if constexpr (WAVES == 8 && TFA_PBS8_PREFETCH) {
+        } else if constexpr (G::kDense && TFA_PBS8_PREFETCH) {
             // Both levels transformed one after the other.  Key words are read from the ring one frequency group ahead,
             // each pair of words (column c, both levels) into the registers that the products of column c have just
             // released, so the reads travel behind the remaining products and the row reduction and cost no extra
@@ -734,7 +736,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
                 oui[k2] = reduce_scatter_rows(pi[0], pi[1], pi[2], pi[3]);
             });
             TFA_STAMP(5);
-        } else if constexpr (WAVES == 8) {
+        } else if constexpr (G::kDense) {
             // both levels transformed one after the other, key words read from the ring as they are used
             fft_forward(f1r, f1i, twl, tr, g, t);
             fft_forward(f2r, f2i, twl, tr, g, t);
@@ -803,7 +805,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES / 4)
                 TFA_STAMP(5);
             }
         }
-        if constexpr (WAVES == 4)
+        if constexpr (!G::kDense)
             fft_inverse2buf(our, oui, twl, tr, tr2, g, t);
         else if constexpr (TFA_INV_TW_PREFETCH && !G::kSplitLevels)
             fft_inverse_pf(our, oui, twl, tr, g, t);
