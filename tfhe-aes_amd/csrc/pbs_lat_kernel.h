@@ -226,10 +226,9 @@ __global__ void __launch_bounds__(256, PER_CU)
 #pragma unroll
         for (int m = 0; m < 8; m++) {
             int jj = 64 * m + L - a;  // (-1024, 512]
-            uint32_t v = rot[jj & 511];
-            v = ((jj >> 9) & 1) ? 0u - v : v;
+            const uint32_t v = rot[jj & 511];
             int d1, d2;
-            decompose2(v - acc[m], d1, d2);
+            rotated_digits(v, jj, acc[m], d1, d2);
             if (m < 4) {
                 zr[0][m] = (double)d1;
                 zr[1][m] = (double)d2;
