@@ -1,0 +1,68 @@
+"""The bootstrap kernels extract both decomposition digits of (sign * v - acc) with a shortened integer sequence
+(rotated_digits in tfhe-aes_amd/csrc/pbs_kernel.h).  This restates that sequence in numpy and checks it against the
+digit rule written out literally (closest representable, then digits from the least significant end with
+carry = res > B/2 or (res == B/2 and bit 9 of the remaining state), the rule the CPU oracle implements in
+oracle/tfhe_oracle.c: orc_decompose) on random inputs and on every rounding / carry boundary."""
+import numpy as np
+
+B_LOG, LEVELS = 10, 2
+
+
+def literal_rule(x):
+    x = x.astype(np.uint64)
+    shift = 32 - B_LOG * LEVELS
+    state = ((x >> np.uint64(shift - 1)) + np.uint64(1)) >> np.uint64(1)
+    state &= np.uint64((1 << (B_LOG * LEVELS)) - 1)
+    digits = []
+    for _ in range(LEVELS):
+        res = state & np.uint64(1023)
+        state = state >> np.uint64(B_LOG)
+        carry = ((((res - np.uint64(1)) | state) & res) >> np.uint64(B_LOG - 1)) & np.uint64(1)  # tfhe-rs: ((res - 1) | state) & res, bit 9
+        state = state + carry
+        digits.append(res.astype(np.int64) - (carry.astype(np.int64) << B_LOG))
+    return digits[1], digits[0]  # (d1 pairs with q / 2^10, d2 with q / 2^20)
+
+
+def kernel_sequence(v, jj, acc):
+    v, acc = v.astype(np.uint32), acc.astype(np.uint32)
+    neg = np.where((jj >> 9) & 1, np.uint32(0xFFFFFFFF), np.uint32(0))
+    with np.errstate(over="ignore"):
+        y = (v ^ neg) - (acc + neg - np.uint32(2048))
+        s, b19 = y >> np.uint32(12), y >> np.uint32(31)
+        u = s + np.uint32(511) + b19
+        d2 = (s - (u & np.uint32(0xFFFFFC00))).astype(np.int32)
+        d1 = (((u + np.uint32(511 << 10)) >> np.uint32(10)) & np.uint32(1023)).astype(np.int32) - 511
+    return d1.astype(np.int64), d2.astype(np.int64)
+
+
+def check(v, jj, acc):
+    with np.errstate(over="ignore"):
+        x = np.where((jj >> 9) & 1, np.uint32(0) - v, v) - acc
+    e1, e2 = literal_rule(x)
+    g1, g2 = kernel_sequence(v, jj, acc)
+    assert (e1 == g1).all() and (e2 == g2).all()
+    # the digits recompose to the closest multiple of q / 2^20, mod 2^32
+    closest = ((x.astype(np.uint64) + np.uint64(2048)) >> np.uint64(12) << np.uint64(12)) & np.uint64(0xFFFFFFFF)
+    assert (((g1 << 22) + (g2 << 12)) % (1 << 32) == closest.astype(np.int64)).all()
+    assert (np.abs(g1) <= 512).all() and (np.abs(g2) <= 512).all()
+
+
+def test_random_inputs():
+    rng = np.random.default_rng(11)
+    n = 1 << 21
+    check(rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32), rng.integers(-1023, 513, n).astype(np.int32),
+          rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32))
+
+
+def test_boundaries():
+    hi = np.arange(1 << 12, dtype=np.uint64)[:, None, None] << np.uint64(20)
+    mid = np.array([0, 0x7FF, 0x800, 0x801, 0xFFF, 0x80000, 0x7FFFF, 0x80800, 0x7F800, 0xFF800], dtype=np.uint64)[None, :, None]
+    lo = np.arange(-3, 4, dtype=np.int64).astype(np.uint64)[None, None, :]
+    x = ((hi + mid + lo) & np.uint64(0xFFFFFFFF)).astype(np.uint32).ravel()
+    zero = np.zeros_like(x)
+    check(x, np.full(x.shape, 5, np.int32), zero)
+    with np.errstate(over="ignore"):
+        check(np.uint32(0) - x, np.full(x.shape, 517, np.int32), zero)       # negated operand
+        check(x + np.uint32(77), np.full(x.shape, -700, np.int32), zero + np.uint32(77))
+    edge = np.concatenate([np.arange(0, 0x3000, dtype=np.uint64), np.arange(0xFFFFD000, 1 << 32, dtype=np.uint64)]).astype(np.uint32)
+    check(edge, np.full(edge.shape, 3, np.int32), np.zeros_like(edge))
