@@ -40,16 +40,35 @@ constexpr int kN = 512;          // polynomial size
 constexpr int kK1 = 4;           // glwe_dimension + 1
 constexpr int kLevels = 2;       // pbs_level
 constexpr int kBaseLog = 10;     // pbs_base_log
-constexpr int kRotStride = 528;  // u32 words per polynomial in the rotation buffer (528 % 32 == 16)
-#ifndef TFA_TR_ROW
-#define TFA_TR_ROW 18
+// Lane mapping.  Quad mode (default): lane = 4 t + g, the four polynomials' lanes for one t are neighbours, so the sum
+// over the polynomials in the key products runs on DPP quad permutes (2 clk per moved dword) instead of the
+// half / row swap instructions (8.5 clk per instruction).  Row mode (TFA_QUAD_LANES=0): lane = 16 g + t.
+#ifndef TFA_EXP_QUAD_SWAPS
+#define TFA_EXP_QUAD_SWAPS 0  // timing/pressure experiment: quad lane mapping with the swap-based reduction (results are garbage)
 #endif
-// doubles per padded transpose row: 18 keeps every row 16-byte aligned, so a lane reads its row with eight conflict-free
-// ds_read_b128 (lane t starts at dword 36 t mod 64: the sixteen lanes of a group cover the 64 banks exactly once);
-// 17 (8-byte reads in pairs, twice the LDS cycles) measured 2 % slower
-constexpr int kTrRow = TFA_TR_ROW;
-constexpr int kTrGroup = 16 * kTrRow;
-constexpr int kWaveLdsBytes = 4 * kTrGroup * 8;  // 9216: transpose buffer (one real plane at a time), aliased by the rotation buffer
+#ifndef TFA_QUAD_LANES
+#define TFA_QUAD_LANES 1
+#endif
+constexpr bool kQuad = TFA_QUAD_LANES != 0;
+__device__ __forceinline__ int lane_g(int lane) { return kQuad ? lane & 3 : lane >> 4; }
+__device__ __forceinline__ int lane_t(int lane) { return kQuad ? lane >> 2 : lane & 15; }
+// u32 words per polynomial in the rotation buffer: the 32 lanes of an LDS access group (8 values of t, 4 of g in quad
+// mode) must fall on 32 different banks: stride = 8 mod 32 (quad) or 16 mod 32 (row)
+constexpr int kRotStride = kQuad ? 520 : 528;
+// Transpose buffer, one real plane of one polynomial per group: lane t stores element r at (row r, column t) and loads
+// its row t.  Row mode pads the rows to 18 doubles (16-byte aligned rows, conflict-free ds_read_b128; 17 with 8-byte
+// reads measured 2 % slower).  Quad mode needs no row padding but a swizzle: column c of row R sits at c ^ 2 (R >> 2),
+// groups 260 doubles apart; found by exhaustive search over paddings and swizzles to be conflict-free for the 8-byte
+// stores (16 consecutive lanes = 4 values of t x 4 groups) and for the 16-byte loads (lane groups of ds_read_b128).
+#ifndef TFA_QUAD_SWIZZLE
+#define TFA_QUAD_SWIZZLE 1  // 0: plain padded rows in quad mode (18 doubles, groups 292 apart): 2-way conflicts on the loads, fewer address registers
+#endif
+constexpr bool kSwz = kQuad && TFA_QUAD_SWIZZLE;
+constexpr int kTrRow = kSwz ? 16 : 18;
+constexpr int kTrGroup = kSwz ? 260 : kQuad ? 292 : 16 * kTrRow;
+__device__ __forceinline__ int tr_store_index(int r, int t) { return kSwz ? r * 16 + (t ^ (2 * (r >> 2))) : r * kTrRow + t; }  // element r of lane t
+__device__ __forceinline__ int tr_load_index(int t, int r) { return kSwz ? t * 16 + (r ^ (2 * (t >> 2))) : t * kTrRow + r; }   // r even: r and r + 1 adjacent
+constexpr int kWaveLdsBytes = (4 * kTrGroup * 8 > 4 * kRotStride * 4) ? 4 * kTrGroup * 8 : 4 * kRotStride * 4;  // transpose buffer, aliased by the rotation buffer
 constexpr int kABytes = 1664;                    // modulus-switched mask, u16[<=832]
 constexpr int kWavePrivBytes = kWaveLdsBytes + kABytes;
 constexpr int kTwBytes = 4096;                   // per-lane twiddle table shared by all waves
@@ -65,6 +84,12 @@ constexpr int kTwBytes = 4096;                   // per-lane twiddle table share
 #define TFA_SCHED_FENCE() ((void)0)
 #else
 #define TFA_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+#ifndef TFA_PIN_GROUP
+#define TFA_PIN_GROUP 1
+#endif
+#ifndef TFA_MAC_STAGGER
+#define TFA_MAC_STAGGER 1
 #endif
 #ifndef TFA_INV_TW_PREFETCH
 #define TFA_INV_TW_PREFETCH 0  // 8 waves: 1 = the inverse transform's twiddles are read before its first DFT16 (measured 4 % slower)
@@ -95,7 +120,7 @@ struct PbsGeom {
     static constexpr int kChunkRows = kDense ? TFA_RING8_ROWS : 16;  // 1 KiB key rows per chunk
     static constexpr int kChunkBytes = kChunkRows * 1024;
     static constexpr int kChunksPerStep = 128 / kChunkRows;
-    static constexpr int kSlots = kDense ? 64 / (kChunkRows * PER_CU) : (kTrRow == 17 ? 5 : 4);
+    static constexpr int kSlots = kDense ? 64 / (kChunkRows * PER_CU) : ((163840 - WAVES * (2 * kWaveLdsBytes + kABytes) - kTwBytes) / 16384 >= 5 ? 5 : 4);
     static constexpr int kRowsPerWave = kChunkRows / WAVES;  // DMA rows each wave issues per chunk
     // one wave per SIMD has no partner wave to hide its LDS round trips, so it gets a second
     // transpose buffer and overlaps two transposes with each other and with arithmetic
@@ -206,7 +231,7 @@ __device__ __forceinline__ void transpose16_plane(double (&v)[16], double *tr, i
 #endif
 #ifndef TFA_EXP_TR_NOWRITE  // timing experiments: one direction of the exchange only (results are garbage)
 #pragma unroll
-    for (int r = 0; r < 16; r++) base[r * kTrRow + t] = v[r];
+    for (int r = 0; r < 16; r++) base[tr_store_index(r, t)] = v[r];
 #else
     {  // keeps the values alive at the price of integer operations and a single store
         uint32_t x = 0;
@@ -219,17 +244,14 @@ __device__ __forceinline__ void transpose16_plane(double (&v)[16], double *tr, i
     wave_lds_fence();
 #endif
 #ifndef TFA_EXP_TR_NOREAD
-    if constexpr (kTrRow % 2 == 0) {  // rows are 16-byte aligned: eight 16-byte reads
+    {  // rows are 16-byte aligned: eight 16-byte reads
         typedef double v2d_ __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
-            const v2d_ x = *reinterpret_cast<const v2d_ *>(base + t * kTrRow + r);
+            const v2d_ x = *reinterpret_cast<const v2d_ *>(base + tr_load_index(t, r));
             v[r] = x.x;
             v[r + 1] = x.y;
         }
-    } else {
-#pragma unroll
-        for (int r = 0; r < 16; r++) v[r] = base[t * kTrRow + r];
     }
 #endif
 }
@@ -315,24 +337,24 @@ __device__ __forceinline__ void fft_forward2(double (&ar)[16], double (&ai)[16],
     double *pa = trA + g * kTrGroup, *pb = trB + g * kTrGroup;
     wave_lds_fence();
 #pragma unroll
-    for (int r = 0; r < 16; r++) pa[r * kTrRow + t] = ar[r];
+    for (int r = 0; r < 16; r++) pa[tr_store_index(r, t)] = ar[r];
 #pragma unroll
-    for (int r = 0; r < 16; r++) pb[r * kTrRow + t] = br[r];
+    for (int r = 0; r < 16; r++) pb[tr_store_index(r, t)] = br[r];
     wave_lds_fence();
 #pragma unroll
-    for (int r = 0; r < 16; r++) ar[r] = pa[t * kTrRow + r];
+    for (int r = 0; r < 16; r++) ar[r] = pa[tr_load_index(t, r & ~1) + (r & 1)];
 #pragma unroll
-    for (int r = 0; r < 16; r++) br[r] = pb[t * kTrRow + r];
+    for (int r = 0; r < 16; r++) br[r] = pb[tr_load_index(t, r & ~1) + (r & 1)];
     wave_lds_fence();
 #pragma unroll
-    for (int r = 0; r < 16; r++) pa[r * kTrRow + t] = ai[r];
+    for (int r = 0; r < 16; r++) pa[tr_store_index(r, t)] = ai[r];
 #pragma unroll
-    for (int r = 0; r < 16; r++) pb[r * kTrRow + t] = bi[r];
+    for (int r = 0; r < 16; r++) pb[tr_store_index(r, t)] = bi[r];
     wave_lds_fence();
 #pragma unroll
-    for (int r = 0; r < 16; r++) ai[r] = pa[t * kTrRow + r];
+    for (int r = 0; r < 16; r++) ai[r] = pa[tr_load_index(t, r & ~1) + (r & 1)];
 #pragma unroll
-    for (int r = 0; r < 16; r++) bi[r] = pb[t * kTrRow + r];
+    for (int r = 0; r < 16; r++) bi[r] = pb[tr_load_index(t, r & ~1) + (r & 1)];
     dft16<1>(ar, ai);
     dft16<1>(br, bi);
 }
@@ -342,14 +364,14 @@ __device__ __forceinline__ void fft_inverse2buf(double (&re)[16], double (&im)[1
     double *pa = trA + g * kTrGroup, *pb = trB + g * kTrGroup;
     wave_lds_fence();
 #pragma unroll
-    for (int r = 0; r < 16; r++) pa[r * kTrRow + t] = re[r];
+    for (int r = 0; r < 16; r++) pa[tr_store_index(r, t)] = re[r];
 #pragma unroll
-    for (int r = 0; r < 16; r++) pb[r * kTrRow + t] = im[r];
+    for (int r = 0; r < 16; r++) pb[tr_store_index(r, t)] = im[r];
     wave_lds_fence();
 #pragma unroll
-    for (int r = 0; r < 16; r++) re[r] = pa[t * kTrRow + r];
+    for (int r = 0; r < 16; r++) re[r] = pa[tr_load_index(t, r & ~1) + (r & 1)];
 #pragma unroll
-    for (int r = 0; r < 16; r++) im[r] = pb[t * kTrRow + r];
+    for (int r = 0; r < 16; r++) im[r] = pb[tr_load_index(t, r & ~1) + (r & 1)];
 #pragma unroll
     for (int k1 = 0; k1 < 16; k1++) {
         c64 w = twl[k1 * 16 + t];
@@ -380,13 +402,33 @@ __device__ __forceinline__ void swap_rows(double &x, double &y) {
     x = __builtin_bit_cast(double, uint2{lo[0], hi[0]});
     y = __builtin_bit_cast(double, uint2{lo[1], hi[1]});
 }
-// Each row g holds partial sums p[c], c = 0..3; afterwards row g holds the total of p[g].
+// Sum over the four polynomials of the partial products, scattered so that polynomial g's lanes end with output g.
+// Row mode: each row g holds partial sums p[c] for outputs c = 0..3.  Quad mode: lane g's p[j] belongs to output
+// j ^ g (the key stores its columns in that order per lane), which makes the exchange the same in every lane:
+// two values from the neighbour at distance 2, then one from the neighbour at distance 1.
+// (the permuted value is built in place: old = source ties the destination to the source's registers)
+__device__ __forceinline__ double quad_from(double x, int ctrl_is_xor1) {
+    uint2 a = __builtin_bit_cast(uint2, x);
+    if (ctrl_is_xor1) {
+        a.x = (uint32_t)__builtin_amdgcn_update_dpp((int)a.x, (int)a.x, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+        a.y = (uint32_t)__builtin_amdgcn_update_dpp((int)a.y, (int)a.y, 0xB1, 0xF, 0xF, false);
+    } else {
+        a.x = (uint32_t)__builtin_amdgcn_update_dpp((int)a.x, (int)a.x, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+        a.y = (uint32_t)__builtin_amdgcn_update_dpp((int)a.y, (int)a.y, 0x4E, 0xF, 0xF, false);
+    }
+    return __builtin_bit_cast(double, a);
+}
 __device__ __forceinline__ double reduce_scatter_rows(double p0, double p1, double p2, double p3) {
-    swap_halves(p0, p2);
-    swap_halves(p1, p3);
-    double sa = p0 + p2, sb = p1 + p3;
-    swap_rows(sa, sb);
-    return sa + sb;
+    if constexpr (kQuad && !TFA_EXP_QUAD_SWAPS) {
+        const double sa = p0 + quad_from(p2, 0), sb = p1 + quad_from(p3, 0);
+        return sa + quad_from(sb, 1);
+    } else {
+        swap_halves(p0, p2);
+        swap_halves(p1, p3);
+        double sa = p0 + p2, sb = p1 + p3;
+        swap_rows(sa, sb);
+        return sa + sb;
+    }
 }
 
 // ---- pinned LDS reads of key words ------------------------------------------------------------
@@ -414,6 +456,14 @@ __device__ __forceinline__ void key_wait(v2d &a, v2d &b, v2d &c, v2d &d, v2d &e,
 __device__ __forceinline__ void pin16(double (&a)[16]) {
     asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
     asm volatile("" : "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]));
+}
+// the four words named have arrived when at most LATER reads issued after them are still travelling
+template <int LATER>
+__device__ __forceinline__ void key_wait_four(v2d &a, v2d &b, v2d &c, v2d &d) {
+    if constexpr (LATER == 4)
+        asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
 }
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F &f, std::integer_sequence<int, I...>) {
@@ -582,7 +632,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES * PER_CU / 4)
     using G = PbsGeom<WAVES, PER_CU>;
     extern __shared__ __align__(16) unsigned char lds[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: keep it (and all ring addressing) scalar
-    const int lane = threadIdx.x & 63, g = lane >> 4, t = lane & 15;
+    const int lane = threadIdx.x & 63, g = lane_g(lane), t = lane_t(lane);
     const uint32_t job_raw = blockIdx.x * WAVES + wave;
     const bool live = job_raw < n_jobs;                 // idle waves of the last workgroup still run the
     const uint32_t job = live ? job_raw : n_jobs - 1;   // loop (barriers, DMA) on a duplicate job, write nothing
@@ -718,6 +768,56 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES * PER_CU / 4)
             constexpr int kPerChunk = G::kChunkRows / 8;  // frequency groups per chunk
             v2d kb[8];                                    // [level * 4 + column]
             uint32_t kaddr;
+#if TFA_MAC_STAGGER
+            // Columns in two pairs: the key registers of a pair are refilled with the next group's words as soon as the
+            // pair's products are done, and each pair waits only for its own four words (the LDS returns reads in
+            // order), so every read has the other pair's products and the row reduction to travel behind.
+            {
+                TFA_RING_ACQUIRE(slot, i * G::kChunksPerStep)
+                kaddr = lds_offset(slot);
+                static_for<4>([&](auto C) __attribute__((always_inline)) {
+                    kb[C.value] = key_read_at<C.value * 1024>(kaddr, 0.0, 0.0);
+                    kb[4 + C.value] = key_read_at<(4 + C.value) * 1024>(kaddr, 0.0, 0.0);
+                });
+            }
+            static_for<16>([&](auto POS) __attribute__((always_inline)) {
+                constexpr int pos = POS.value, k2 = kperm(pos), kk = (pos + 1) % kPerChunk;
+                constexpr bool kMore = pos + 1 < 16, kOpens = kMore && kk == 0;
+                if constexpr (kOpens) {  // next group opens the next chunk: this wave must hold all of the current one first
+                    key_wait(kb[0], kb[1], kb[2], kb[3], kb[4], kb[5], kb[6], kb[7]);
+                    TFA_RING_ACQUIRE(slot, i * G::kChunksPerStep + (pos + 1) / kPerChunk)
+                    kaddr = lds_offset(slot);
+                } else {
+                    key_wait_four<4>(kb[0], kb[4], kb[1], kb[5]);
+                }
+                double pr[4], pi[4];
+                static_for<2>([&](auto H) __attribute__((always_inline)) {
+                    constexpr int h = H.value;
+                    if constexpr (h == 1 && !kOpens) key_wait_four<kMore ? 4 : 0>(kb[2], kb[6], kb[3], kb[7]);
+                    static_for<2>([&](auto C) __attribute__((always_inline)) {
+                        constexpr int c = 2 * h + C.value;
+                        const v2d b0 = kb[c], b1 = kb[4 + c];
+                        pr[c] = f1r[k2] * b0.x - f1i[k2] * b0.y + f2r[k2] * b1.x - f2i[k2] * b1.y;
+                        pi[c] = f1r[k2] * b0.y + f1i[k2] * b0.x + f2r[k2] * b1.y + f2i[k2] * b1.x;
+                    });
+                    if constexpr (kMore) {
+                        static_for<2>([&](auto C) __attribute__((always_inline)) {
+                            constexpr int c = 2 * h + C.value;
+                            kb[c] = key_read_at<(kk * 8 + c) * 1024>(kaddr, pr[2 * h], pi[2 * h + 1]);
+                            kb[4 + c] = key_read_at<(kk * 8 + 4 + c) * 1024>(kaddr, pr[2 * h + 1], pi[2 * h]);
+                        });
+                    }
+                    // the second pair's products start behind the first pair's reads
+                    if constexpr (h == 0) asm volatile("" : "+v"(f1r[k2]), "+v"(f1i[k2]), "+v"(f2r[k2]), "+v"(f2i[k2]));
+                });
+                our[k2] = reduce_scatter_rows(pr[0], pr[1], pr[2], pr[3]);
+                oui[k2] = reduce_scatter_rows(pi[0], pi[1], pi[2], pi[3]);
+#if TFA_PIN_GROUP
+                // the group's sums exist before the next group's waits: keeps two groups' partial sums from being live together
+                asm volatile("" : "+v"(our[k2]), "+v"(oui[k2]));
+#endif
+            });
+#else
             {
                 TFA_RING_ACQUIRE(slot, i * G::kChunksPerStep)
                 kaddr = lds_offset(slot);
@@ -746,6 +846,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES * PER_CU / 4)
                 our[k2] = reduce_scatter_rows(pr[0], pr[1], pr[2], pr[3]);
                 oui[k2] = reduce_scatter_rows(pi[0], pi[1], pi[2], pi[3]);
             });
+#endif
             TFA_STAMP(5);
         } else if constexpr (G::kDense) {
             // both levels transformed one after the other, key words read from the ring as they are used
@@ -855,7 +956,7 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES * PER_CU / 4)
 __global__ void __launch_bounds__(256, 1)
     bsk_convert_kernel(const uint32_t *__restrict__ bsk, c64 *__restrict__ bsk_f, const c64 *__restrict__ tw, uint32_t n_rows) {
     extern __shared__ __align__(16) unsigned char lds[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, t = lane & 15;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane_g(lane), t = lane_t(lane);
     const uint32_t row = blockIdx.x * kConvertWaves + wave;  // (i * l + lv) * 4 + r
     if (row >= n_rows) return;
     double *tr = reinterpret_cast<double *>(lds + wave * kWavePrivBytes);
@@ -868,8 +969,11 @@ __global__ void __launch_bounds__(256, 1)
     }
     fft_forward(re, im, tw, tr, g, t);
     const uint32_t r = row & 3, lv = (row >> 2) % kLevels, i = (row >> 2) / kLevels;
+    // destination: the lane of the bootstrap kernel that owns input polynomial r and frequency lane t; in quad mode that
+    // lane keeps column g in slot g ^ r (see reduce_scatter_rows)
+    const int dst_lane = kQuad ? 4 * t + (int)r : (int)r * 16 + t, slot = kQuad ? (g ^ (int)r) : g;
 #pragma unroll
-    for (int k2 = 0; k2 < 16; k2++) bsk_f[bsk_index(i, lv, kperm(k2), g) + r * 16 + t] = c64{re[k2] * (1.0 / 256.0), im[k2] * (1.0 / 256.0)};
+    for (int k2 = 0; k2 < 16; k2++) bsk_f[bsk_index(i, lv, kperm(k2), slot) + dst_lane] = c64{re[k2] * (1.0 / 256.0), im[k2] * (1.0 / 256.0)};
 }
 
 }  // namespace tfa
