@@ -85,6 +85,9 @@ constexpr int kTwBytes = 4096;                   // per-lane twiddle table share
 #else
 #define TFA_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
+#ifndef TFA_PIN_GROUP4
+#define TFA_PIN_GROUP4 1
+#endif
 #ifndef TFA_PIN_GROUP
 #define TFA_PIN_GROUP 1
 #endif
@@ -913,6 +916,9 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES * PER_CU / 4)
                     }
                     our[k2] = reduce_scatter_rows(pr[0], pr[1], pr[2], pr[3]);
                     oui[k2] = reduce_scatter_rows(pi[0], pi[1], pi[2], pi[3]);
+#if TFA_PIN_GROUP4
+                    asm volatile("" : "+v"(our[k2]), "+v"(oui[k2]));
+#endif
                 }
                 TFA_STAMP(5);
             }
