@@ -39,9 +39,10 @@ def measured_traffic():
     cannot be collected inside a timed run, so this is the profile's number, or None without the file."""
     try:
         with open(os.path.join(ROOT, "profiles", "r1_pmc_summary.json")) as f:
-            c = json.load(f)["counters_current_kernels"]["tfa::pbs_kernel<8>"]
+            cur = json.load(f)["counters_current_kernels"]
+        c = next(v for k, v in cur.items() if k.startswith("tfa::pbs_kernel<8"))
         return int((2 * c["FETCH_SIZE@65536"] + c["WRITE_SIZE@65536"]) * 1024)
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, StopIteration):
         return None
 
 

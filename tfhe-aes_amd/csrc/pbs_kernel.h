@@ -217,6 +217,13 @@ __device__ __forceinline__ void dft16(double (&re)[16], double (&im)[16]) {
     }
 }
 
+// Forces the 16 values to exist in registers at this point of the program (an empty instruction that "modifies" them):
+// keeps the compiler from evaluating the tail of a transform lazily inside the code that follows, which stretches the
+// live ranges of the transform's inputs over that code.
+__device__ __forceinline__ void pin16(double (&a)[16]) {
+    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+    asm volatile("" : "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]));
+}
 // e^{i pi n/32}, n = 0..15: the lane-independent part of the negacyclic twist
 __device__ constexpr double kC32[16] = {1.0, 0.9951847266721969, 0.9807852804032304, 0.9569403357322088, 0.9238795325112867, 0.881921264348355,
                                         0.8314696123025452, 0.773010453362737, 0.7071067811865476, 0.6343932841636455, 0.5555702330196023,
@@ -318,6 +325,34 @@ __device__ __forceinline__ void fft_forward_pair(double (&ar)[16], double (&ai)[
     transpose16(ar, ai, tr, g, t);
     transpose16(br, bi, tr, g, t);
     dft16<1>(ar, ai);
+    dft16<1>(br, bi);
+}
+// Two forward transforms on one transpose buffer, ordered so that each one's exchange travels behind the other's
+// arithmetic: twiddles and exchange of a, twiddles of b (cover for a), exchange of b, second DFT16 of a (cover for b).
+__device__ __forceinline__ void fft_forward_pair_ordered(double (&ar)[16], double (&ai)[16], double (&br)[16], double (&bi)[16], const c64 *twl,
+                                                         double *tr, int g, int t) {
+#pragma unroll
+    for (int n1 = 1; n1 < 16; n1++) {
+        cmulc<1>(ar[n1], ai[n1], kC32[n1], kS32[n1]);
+        cmulc<1>(br[n1], bi[n1], kC32[n1], kS32[n1]);
+    }
+    dft16<1>(ar, ai);
+    dft16<1>(br, bi);
+#pragma unroll
+    for (int k1 = 0; k1 < 16; k1++) {
+        c64 w = twl[k1 * 16 + t];
+        cmulc<1>(ar[k1], ai[k1], w.x, w.y);
+    }
+    transpose16(ar, ai, tr, g, t);
+#pragma unroll
+    for (int k1 = 0; k1 < 16; k1++) {
+        c64 w = twl[k1 * 16 + t];
+        cmulc<1>(br[k1], bi[k1], w.x, w.y);
+    }
+    pin16(br), pin16(bi);  // b's twiddle products are done (they are a's cover) before b's exchange starts
+    transpose16(br, bi, tr, g, t);
+    dft16<1>(ar, ai);
+    pin16(ar), pin16(ai);
     dft16<1>(br, bi);
 }
 // Two independent forward transforms interleaved (two transpose buffers): the LDS round trips of one
@@ -452,13 +487,6 @@ __device__ __forceinline__ v2d key_read_at(uint32_t addr, double dep0, double de
 }
 __device__ __forceinline__ void key_wait(v2d &a, v2d &b, v2d &c, v2d &d, v2d &e, v2d &f, v2d &g, v2d &h) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
-}
-// Forces the 16 values to exist in registers at this point of the program (an empty instruction that "modifies" them):
-// keeps the compiler from evaluating the tail of a transform lazily inside the code that follows, which stretches the
-// live ranges of the transform's inputs over that code.
-__device__ __forceinline__ void pin16(double (&a)[16]) {
-    asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
-    asm volatile("" : "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]));
 }
 // the four words named have arrived when at most LATER reads issued after them are still travelling
 template <int LATER>
@@ -758,7 +786,9 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES * PER_CU / 4)
             // released, so the reads travel behind the remaining products and the row reduction and cost no extra
             // registers.  The reads are inline asm pinned after those products by (unused) operands; the compiler does
             // not count them, so every group starts with an explicit wait.
-#if TFA_FFT_PAIR
+#if TFA_FFT_PAIR == 2
+            fft_forward_pair_ordered(f1r, f1i, f2r, f2i, twl, tr, g, t);
+#elif TFA_FFT_PAIR
             fft_forward_pair(f1r, f1i, f2r, f2i, twl, tr, g, t);
 #else
             fft_forward(f1r, f1i, twl, tr, g, t);
