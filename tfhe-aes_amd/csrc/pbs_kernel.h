@@ -1,13 +1,12 @@
 // Programmable bootstrap (gate linear combination + modulus switch + blind rotation + sample
 // extract) for gfx950, specialised for k = 3, N = 512, (beta, l) = (2^10, 2).
 //
-// Mapping: one 64-lane wavefront owns one bootstrap for all n blind-rotation steps.  The four
-// 16-lane rows of the wave (g = lane >> 4) each own one polynomial of the GLWE accumulator; lane
-// t = lane & 15 of a row holds the 32 coefficients j == t (mod 16) in registers.  A negacyclic
-// size-512 transform is a size-256 complex FFT computed as 16 x 16: a register-resident DFT16 per
-// lane, one 16 x 16 transpose through wave-private LDS, a second register DFT16.  The Fourier
-// domain multiply-accumulate with the bootstrapping key sums over the four rows with the gfx950
-// row/half swap instructions.  The waves of a workgroup advance in lock step and share the
+// Mapping: one 64-lane wavefront owns one bootstrap for all n blind-rotation steps.  Lane = 4 t + g: the sixteen lanes
+// with the same g = lane & 3 own polynomial g of the GLWE accumulator; lane t = lane >> 2 holds the 32 coefficients
+// j == t (mod 16) in registers.  A negacyclic size-512 transform is a size-256 complex FFT computed as 16 x 16: a
+// register-resident DFT16 per lane, one 16 x 16 transpose through wave-private LDS, a second register DFT16.  The
+// Fourier domain multiply-accumulate with the bootstrapping key sums over the four polynomials inside each quad of
+// neighbouring lanes with DPP quad permutes.  The waves of a workgroup advance in lock step and share the
 // bootstrapping key through an LDS ring filled by LDS-DMA, one barrier per 16 KiB chunk.
 //
 // What the kernel computes follows tfhe-rs 0.11 (blind_rotate_assign / add_external_product_assign,
