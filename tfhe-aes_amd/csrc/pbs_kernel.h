@@ -231,6 +231,123 @@ __device__ constexpr double kS32[16] = {0.0, 0.0980171403295606, 0.1950903220161
                                         0.5555702330196022, 0.6343932841636455, 0.7071067811865475, 0.773010453362737, 0.8314696123025452,
                                         0.8819212643483549, 0.9238795325112867, 0.9569403357322089, 0.9807852804032304, 0.9951847266721968};
 
+// ---- register DFT16 with the twiddle scalings folded into the butterflies' fused multiply-adds ------------------
+// A twiddle w = c (1 + i S tau) costs two instructions (the "1 + i S tau" part, rot_tan) instead of four: the real
+// scale c rides on the multiply-add that consumes the value.
+template <int S>
+__device__ __forceinline__ void rot_tan(double &r, double &i, double tau) {  // (r + i i) * (1 + i S tau)
+    const double st = S > 0 ? tau : -tau;
+    const double nr = __builtin_fma(-st, i, r), ni = __builtin_fma(st, r, i);
+    r = nr;
+    i = ni;
+}
+// DFT4 of x0, c1 u1, c2 u2, c3 u3 (x0 unscaled), results in place
+template <int S>
+__device__ __forceinline__ void dft4_scaled(double &r0, double &i0, double &r1, double &i1, double c1, double &r2, double &i2, double c2, double &r3,
+                                            double &i3, double c3) {
+    const double q = c3 / c1, sc = S > 0 ? c1 : -c1;
+    const double t0r = __builtin_fma(c2, r2, r0), t0i = __builtin_fma(c2, i2, i0), t1r = __builtin_fma(-c2, r2, r0), t1i = __builtin_fma(-c2, i2, i0);
+    const double t2r = __builtin_fma(q, r3, r1), t2i = __builtin_fma(q, i3, i1), dr = __builtin_fma(-q, r3, r1), di = __builtin_fma(-q, i3, i1);
+    r0 = __builtin_fma(c1, t2r, t0r);
+    i0 = __builtin_fma(c1, t2i, t0i);
+    r2 = __builtin_fma(-c1, t2r, t0r);
+    i2 = __builtin_fma(-c1, t2i, t0i);
+    r1 = __builtin_fma(-sc, di, t1r);  // t1 + S i c1 d
+    i1 = __builtin_fma(sc, dr, t1i);
+    r3 = __builtin_fma(sc, di, t1r);
+    i3 = __builtin_fma(-sc, dr, t1i);
+}
+// the same with x0 = c0 u0 scaled as well
+template <int S>
+__device__ __forceinline__ void dft4_allscaled(double &r0, double &i0, double c0, double &r1, double &i1, double c1, double &r2, double &i2, double c2,
+                                               double &r3, double &i3, double c3) {
+    r0 *= c0;
+    i0 *= c0;
+    dft4_scaled<S>(r0, i0, r1, i1, c1, r2, i2, c2, r3, i3, c3);
+}
+// TWIST (forward transforms only, S = +1): the inputs are first multiplied by e^{i pi n / 32}
+template <int S, bool TWIST>
+__device__ __forceinline__ void dft16m(double (&re)[16], double (&im)[16]) {
+    constexpr double C1 = 0.9238795325112867, S1 = 0.3826834323650898, R = 0.7071067811865476;
+    constexpr double T1 = S1 / C1, T3 = C1 / S1;  // tan(pi/8), tan(3 pi/8)
+    static_assert(!TWIST || S > 0, "the twist belongs to the forward transform");
+#pragma unroll
+    for (int n2 = 0; n2 < 4; n2++) {
+        if constexpr (!TWIST) {
+            dft4<S>(re[n2], im[n2], re[4 + n2], im[4 + n2], re[8 + n2], im[8 + n2], re[12 + n2], im[12 + n2]);
+        } else {
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+                if (n2 + 4 * a > 0) rot_tan<1>(re[n2 + 4 * a], im[n2 + 4 * a], kS32[n2 + 4 * a] / kC32[n2 + 4 * a]);
+            if (n2 == 0)
+                dft4_scaled<1>(re[0], im[0], re[4], im[4], kC32[4], re[8], im[8], kC32[8], re[12], im[12], kC32[12]);
+            else
+                dft4_allscaled<1>(re[n2], im[n2], kC32[n2], re[4 + n2], im[4 + n2], kC32[4 + n2], re[8 + n2], im[8 + n2], kC32[8 + n2], re[12 + n2],
+                                  im[12 + n2], kC32[12 + n2]);
+        }
+    }
+    // position 4*k1 + n2 now holds u[n2][k1]; the twiddles W16^(n2*k1) = c (1 + i S tau) go into the second layer
+    dft4<S>(re[0], im[0], re[1], im[1], re[2], im[2], re[3], im[3]);
+    // k1 = 1: e = 1, 2, 3
+    rot_tan<S>(re[5], im[5], T1);
+    rot_tan<S>(re[6], im[6], 1.0);
+    rot_tan<S>(re[7], im[7], T3);
+    dft4_scaled<S>(re[4], im[4], re[5], im[5], C1, re[6], im[6], R, re[7], im[7], S1);
+    // k1 = 2: e = 2, 4 (times S i: a rotation by a quarter turn, no arithmetic), 6
+    rot_tan<S>(re[9], im[9], 1.0);
+    {
+        const double r = re[10], i = im[10];
+        re[10] = S > 0 ? -i : i;
+        im[10] = S > 0 ? r : -r;
+    }
+    rot_tan<S>(re[11], im[11], -1.0);
+    dft4_scaled<S>(re[8], im[8], re[9], im[9], R, re[10], im[10], 1.0, re[11], im[11], -R);
+    // k1 = 3: e = 3, 6, 9
+    rot_tan<S>(re[13], im[13], T3);
+    rot_tan<S>(re[14], im[14], -1.0);
+    rot_tan<S>(re[15], im[15], T1);
+    dft4_scaled<S>(re[12], im[12], re[13], im[13], S1, re[14], im[14], -R, re[15], im[15], -C1);
+    // position 4*k1 + k2 holds X[k1 + 4*k2]: undo the digit reversal (register renaming only)
+    double tr[16], ti[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        tr[k] = re[4 * (k & 3) + (k >> 2)];
+        ti[k] = im[4 * (k & 3) + (k >> 2)];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        re[k] = tr[k];
+        im[k] = ti[k];
+    }
+}
+// Which DFT16s use the folded form, as a bit mask: 1 = first of a forward transform (after the twist), 2 = second of a
+// forward transform, 4 = both of an inverse transform, 8 = the twist folded into the first forward DFT16 as well.
+// All forms give the same values to rounding; measured on the 8-wave kernel the folded forms issue up to 120 fewer fp64
+// instructions per step but make the compiler serialise the LDS reads of the step (one read, one wait), which costs
+// more than the instructions save (mask 7: 167 k against 187 k bootstraps/s; mask 15 also spills 170 scalar registers).
+#ifndef TFA_FMA_DFT
+#define TFA_FMA_DFT 0
+#endif
+__device__ __forceinline__ void dft16_twisted(double (&re)[16], double (&im)[16]) {  // first DFT16 of a forward transform, twist included
+    if constexpr ((TFA_FMA_DFT & 8) != 0) {
+        dft16m<1, true>(re, im);
+    } else {
+#pragma unroll
+        for (int n1 = 1; n1 < 16; n1++) cmulc<1>(re[n1], im[n1], kC32[n1], kS32[n1]);
+        if constexpr ((TFA_FMA_DFT & 1) != 0)
+            dft16m<1, false>(re, im);
+        else
+            dft16<1>(re, im);
+    }
+}
+template <int S>
+__device__ __forceinline__ void dft16_plain(double (&re)[16], double (&im)[16]) {  // the other DFT16s
+    if constexpr ((TFA_FMA_DFT & (S > 0 ? 2 : 4)) != 0)
+        dft16m<S, false>(re, im);
+    else
+        dft16<S>(re, im);
+}
+
 // 16 x 16 transpose inside each row of 16 lanes through the wave-private LDS buffer, one real
 // plane at a time: lane t writes element r to [g][r][t] and reads back [g][t][r].
 __device__ __forceinline__ void transpose16_plane(double (&v)[16], double *tr, int g, int t) {
@@ -279,27 +396,25 @@ __device__ __forceinline__ void transpose16(double (&re)[16], double (&im)[16], 
 // coefficients (re = coefficient 16*n1 + t, im = coefficient 16*n1 + t + 256).  Output: lane k1 = t
 // holds frequency bins k1 + 16*k2, k2 = 0..15.
 __device__ __forceinline__ void fft_forward(double (&re)[16], double (&im)[16], const c64 *twl, double *tr, int g, int t) {
-#pragma unroll
-    for (int n1 = 1; n1 < 16; n1++) cmulc<1>(re[n1], im[n1], kC32[n1], kS32[n1]);
-    dft16<1>(re, im);
+    dft16_twisted(re, im);
 #pragma unroll
     for (int k1 = 0; k1 < 16; k1++) {
         c64 w = twl[k1 * 16 + t];
         cmulc<1>(re[k1], im[k1], w.x, w.y);
     }
     transpose16(re, im, tr, g, t);
-    dft16<1>(re, im);
+    dft16_plain<1>(re, im);
 }
 // Inverse of fft_forward without the 1/256 (folded into the Fourier key).
 __device__ __forceinline__ void fft_inverse(double (&re)[16], double (&im)[16], const c64 *twl, double *tr, int g, int t) {
-    dft16<-1>(re, im);
+    dft16_plain<-1>(re, im);
     transpose16(re, im, tr, g, t);
 #pragma unroll
     for (int k1 = 0; k1 < 16; k1++) {
         c64 w = twl[k1 * 16 + t];
         cmulc<-1>(re[k1], im[k1], w.x, w.y);
     }
-    dft16<-1>(re, im);
+    dft16_plain<-1>(re, im);
 #pragma unroll
     for (int n1 = 1; n1 < 16; n1++) cmulc<-1>(re[n1], im[n1], kC32[n1], kS32[n1]);
 }
@@ -308,13 +423,8 @@ __device__ __forceinline__ void fft_inverse(double (&re)[16], double (&im)[16], 
 // dependency chains interleave.  Used by the two-waves-per-SIMD variant.
 __device__ __forceinline__ void fft_forward_pair(double (&ar)[16], double (&ai)[16], double (&br)[16], double (&bi)[16], const c64 *twl, double *tr,
                                                  int g, int t) {
-#pragma unroll
-    for (int n1 = 1; n1 < 16; n1++) {
-        cmulc<1>(ar[n1], ai[n1], kC32[n1], kS32[n1]);
-        cmulc<1>(br[n1], bi[n1], kC32[n1], kS32[n1]);
-    }
-    dft16<1>(ar, ai);
-    dft16<1>(br, bi);
+    dft16_twisted(ar, ai);
+    dft16_twisted(br, bi);
 #pragma unroll
     for (int k1 = 0; k1 < 16; k1++) {
         c64 w = twl[k1 * 16 + t];
@@ -323,20 +433,15 @@ __device__ __forceinline__ void fft_forward_pair(double (&ar)[16], double (&ai)[
     }
     transpose16(ar, ai, tr, g, t);
     transpose16(br, bi, tr, g, t);
-    dft16<1>(ar, ai);
-    dft16<1>(br, bi);
+    dft16_plain<1>(ar, ai);
+    dft16_plain<1>(br, bi);
 }
 // Two forward transforms on one transpose buffer, ordered so that each one's exchange travels behind the other's
 // arithmetic: twiddles and exchange of a, twiddles of b (cover for a), exchange of b, second DFT16 of a (cover for b).
 __device__ __forceinline__ void fft_forward_pair_ordered(double (&ar)[16], double (&ai)[16], double (&br)[16], double (&bi)[16], const c64 *twl,
                                                          double *tr, int g, int t) {
-#pragma unroll
-    for (int n1 = 1; n1 < 16; n1++) {
-        cmulc<1>(ar[n1], ai[n1], kC32[n1], kS32[n1]);
-        cmulc<1>(br[n1], bi[n1], kC32[n1], kS32[n1]);
-    }
-    dft16<1>(ar, ai);
-    dft16<1>(br, bi);
+    dft16_twisted(ar, ai);
+    dft16_twisted(br, bi);
 #pragma unroll
     for (int k1 = 0; k1 < 16; k1++) {
         c64 w = twl[k1 * 16 + t];
@@ -350,21 +455,16 @@ __device__ __forceinline__ void fft_forward_pair_ordered(double (&ar)[16], doubl
     }
     pin16(br), pin16(bi);  // b's twiddle products are done (they are a's cover) before b's exchange starts
     transpose16(br, bi, tr, g, t);
-    dft16<1>(ar, ai);
+    dft16_plain<1>(ar, ai);
     pin16(ar), pin16(ai);
-    dft16<1>(br, bi);
+    dft16_plain<1>(br, bi);
 }
 // Two independent forward transforms interleaved (two transpose buffers): the LDS round trips of one
 // overlap the arithmetic of the other.  Used by the one-wave-per-SIMD variant.
 __device__ __forceinline__ void fft_forward2(double (&ar)[16], double (&ai)[16], double (&br)[16], double (&bi)[16], const c64 *twl, double *trA,
                                              double *trB, int g, int t) {
-#pragma unroll
-    for (int n1 = 1; n1 < 16; n1++) {
-        cmulc<1>(ar[n1], ai[n1], kC32[n1], kS32[n1]);
-        cmulc<1>(br[n1], bi[n1], kC32[n1], kS32[n1]);
-    }
-    dft16<1>(ar, ai);
-    dft16<1>(br, bi);
+    dft16_twisted(ar, ai);
+    dft16_twisted(br, bi);
 #pragma unroll
     for (int k1 = 0; k1 < 16; k1++) {
         c64 w = twl[k1 * 16 + t];
@@ -392,12 +492,12 @@ __device__ __forceinline__ void fft_forward2(double (&ar)[16], double (&ai)[16],
     for (int r = 0; r < 16; r++) ai[r] = pa[tr_load_index(t, r & ~1) + (r & 1)];
 #pragma unroll
     for (int r = 0; r < 16; r++) bi[r] = pb[tr_load_index(t, r & ~1) + (r & 1)];
-    dft16<1>(ar, ai);
-    dft16<1>(br, bi);
+    dft16_plain<1>(ar, ai);
+    dft16_plain<1>(br, bi);
 }
 // Inverse transform with the real and imaginary planes in separate buffers (no wait between planes).
 __device__ __forceinline__ void fft_inverse2buf(double (&re)[16], double (&im)[16], const c64 *twl, double *trA, double *trB, int g, int t) {
-    dft16<-1>(re, im);
+    dft16_plain<-1>(re, im);
     double *pa = trA + g * kTrGroup, *pb = trB + g * kTrGroup;
     wave_lds_fence();
 #pragma unroll
@@ -414,7 +514,7 @@ __device__ __forceinline__ void fft_inverse2buf(double (&re)[16], double (&im)[1
         c64 w = twl[k1 * 16 + t];
         cmulc<-1>(re[k1], im[k1], w.x, w.y);
     }
-    dft16<-1>(re, im);
+    dft16_plain<-1>(re, im);
 #pragma unroll
     for (int n1 = 1; n1 < 16; n1++) cmulc<-1>(re[n1], im[n1], kC32[n1], kS32[n1]);
 }
@@ -510,13 +610,13 @@ __device__ __forceinline__ void fft_inverse_pf(double (&re)[16], double (&im)[16
     v2d w[16];
     const uint32_t waddr = lds_offset(twl + t);
     static_for<16>([&](auto K) __attribute__((always_inline)) { w[K.value] = key_read_at<K.value * 256>(waddr, re[15], im[15]); });
-    dft16<-1>(re, im);
+    dft16_plain<-1>(re, im);
     transpose16(re, im, tr, g, t);
     key_wait(w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]);
     key_wait(w[8], w[9], w[10], w[11], w[12], w[13], w[14], w[15]);
 #pragma unroll
     for (int k1 = 0; k1 < 16; k1++) cmulc<-1>(re[k1], im[k1], w[k1].x, w[k1].y);
-    dft16<-1>(re, im);
+    dft16_plain<-1>(re, im);
 #pragma unroll
     for (int n1 = 1; n1 < 16; n1++) cmulc<-1>(re[n1], im[n1], kC32[n1], kS32[n1]);
 }
