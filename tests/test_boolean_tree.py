@@ -51,7 +51,7 @@ def test_reduce_mux_evaluates_like_the_fold(levels):
         assert H.reduce_mux(tab) == B.to_string(e)
 
 
-@pytest.mark.parametrize("name,table", [("sbox", B.S_BOX), ("inv_sbox", B.INV_S_BOX)])
+@pytest.mark.parametrize("name,table", [("sbox", B.S_BOX), ("inv_sbox", B.INV_S_BOX)], ids=["sbox", "inv_sbox"])
 def test_sbox_circuits_exhaustive(name, table):
     roots = B.generate_reduced_bool_expr(table)
     for x in range(256):
@@ -72,7 +72,7 @@ EXPECTED = {  # stage histogram and gate kinds (And, Or, Xor, Mux) of the two ci
 }
 
 
-@pytest.mark.parametrize("name,table", [("sbox", B.S_BOX), ("inv_sbox", B.INV_S_BOX)])
+@pytest.mark.parametrize("name,table", [("sbox", B.S_BOX), ("inv_sbox", B.INV_S_BOX)], ids=["sbox", "inv_sbox"])
 def test_gate_bill_and_host_mirror_identity(name, table):
     roots = B.generate_reduced_bool_expr(table)
     stages = B.staged(roots)
