@@ -40,8 +40,8 @@ constexpr int kK1 = 4;           // glwe_dimension + 1
 constexpr int kLevels = 2;       // pbs_level
 constexpr int kBaseLog = 10;     // pbs_base_log
 // Lane mapping.  Quad mode (default): lane = 4 t + g, the four polynomials' lanes for one t are neighbours, so the sum
-// over the polynomials in the key products runs on DPP quad permutes (2 clk per moved dword) instead of the
-// half / row swap instructions (8.5 clk per instruction).  Row mode (TFA_QUAD_LANES=0): lane = 16 g + t.
+// over the polynomials in the key products runs on DPP quad permutes (4.5 clk per moved dword at two waves per SIMD,
+// in place) instead of the half / row swap instructions (8.6 clk per instruction).  Row mode (TFA_QUAD_LANES=0): lane = 16 g + t.
 #ifndef TFA_EXP_QUAD_SWAPS
 #define TFA_EXP_QUAD_SWAPS 0  // timing/pressure experiment: quad lane mapping with the swap-based reduction (results are garbage)
 #endif

@@ -58,6 +58,30 @@ __global__ void __launch_bounds__(256) k_rate(double* out, int iters) {
     } else if (MODE == 7) {  // v_mad_u32_u24 / plain add
 #pragma unroll
       for (int j = 0; j < 16; j++) { u0 += u1; u1 ^= u2; u2 += u3; u3 ^= u0; }
+    } else if (MODE == 8) {  // fma f64 with three vector operands
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        x0 = fma(x1, x2, x0); x1 = fma(x2, x3, x1); x2 = fma(x3, x4, x2); x3 = fma(x4, x5, x3);
+        x4 = fma(x5, x6, x4); x5 = fma(x6, x7, x5); x6 = fma(x7, x0, x6); x7 = fma(x0, x1, x7);
+      }
+    } else if (MODE == 9) {  // add f64 with two vector operands
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        x0 += x4; x1 += x5; x2 += x6; x3 += x7; x4 += x1; x5 += x2; x6 += x3; x7 += x0;
+        asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+      }
+    } else if (MODE == 10) {  // fma f64: scalar constant times vector plus vector (the folded butterfly form)
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        x0 = fma(c, x4, x0); x1 = fma(c, x5, x1); x2 = fma(c, x6, x2); x3 = fma(c, x7, x3);
+        x4 = fma(c, x1, x4); x5 = fma(c, x2, x5); x6 = fma(c, x3, x6); x7 = fma(c, x0, x7);
+      }
+    } else if (MODE == 11) {  // DPP quad permute moves
+#pragma unroll
+      for (int j = 0; j < 16; j++) {
+        u0 = (unsigned)__builtin_amdgcn_update_dpp((int)u0, (int)u0, 0x4E, 0xF, 0xF, false); u1 = (unsigned)__builtin_amdgcn_update_dpp((int)u1, (int)u1, 0xB1, 0xF, 0xF, false);
+        u2 = (unsigned)__builtin_amdgcn_update_dpp((int)u2, (int)u2, 0x4E, 0xF, 0xF, false); u3 = (unsigned)__builtin_amdgcn_update_dpp((int)u3, (int)u3, 0xB1, 0xF, 0xF, false);
+      }
     } else if (MODE == 4) {  // v_mul_lo_u32
 #pragma unroll
       for (int j = 0; j < 16; j++) { u0 = u0 * u1 + 1; u1 = u1 * u2 + 1; u2 = u2 * u3 + 1; u3 = u3 * u0 + 1; }
@@ -100,6 +124,7 @@ int main() {
     rate<0>("fma_f64", 64, blocks, th); rate<1>("add_f64", 64, blocks, th); rate<3>("mul_f64", 64, blocks, th);
     rate<2>("permlane_swap", 64, blocks, th); rate<4>("mul_lo_u32", 64, blocks, th); rate<5>("mix_fma_int", 128, blocks, th);
     rate<6>("dot4_i8", 64, blocks, th); rate<7>("int_add_xor", 64, blocks, th);
+    rate<8>("fma_f64_vvv", 64, blocks, th); rate<9>("add_f64_vv", 64, blocks, th); rate<10>("fma_f64_svv", 64, blocks, th); rate<11>("dpp_quad_mov", 64, blocks, th);
   }
   return 0;
 }
