@@ -381,9 +381,16 @@ __device__ __forceinline__ void transpose16_plane(double (&v)[16], double *tr, i
     }
 #endif
 }
+template <bool INVERSE = false>
 __device__ __forceinline__ void transpose16(double (&re)[16], double (&im)[16], double *tr, int g, int t) {
 #ifdef TFA_EXP_NOTRANSPOSE  // timing experiment: no exchange between the two DFT16 (results are garbage)
     return;
+#endif
+#ifdef TFA_EXP_NOTR_FWD  // ... in the forward / in the inverse transforms only
+    if (!INVERSE) return;
+#endif
+#ifdef TFA_EXP_NOTR_INV
+    if (INVERSE) return;
 #endif
 #if !TFA_TR_FENCES
     wave_lds_fence();  // orders the exchange after earlier accesses to the aliased rotation buffer (other element type)
@@ -408,7 +415,7 @@ __device__ __forceinline__ void fft_forward(double (&re)[16], double (&im)[16], 
 // Inverse of fft_forward without the 1/256 (folded into the Fourier key).
 __device__ __forceinline__ void fft_inverse(double (&re)[16], double (&im)[16], const c64 *twl, double *tr, int g, int t) {
     dft16_plain<-1>(re, im);
-    transpose16(re, im, tr, g, t);
+    transpose16<true>(re, im, tr, g, t);
 #pragma unroll
     for (int k1 = 0; k1 < 16; k1++) {
         c64 w = twl[k1 * 16 + t];
@@ -611,7 +618,7 @@ __device__ __forceinline__ void fft_inverse_pf(double (&re)[16], double (&im)[16
     const uint32_t waddr = lds_offset(twl + t);
     static_for<16>([&](auto K) __attribute__((always_inline)) { w[K.value] = key_read_at<K.value * 256>(waddr, re[15], im[15]); });
     dft16_plain<-1>(re, im);
-    transpose16(re, im, tr, g, t);
+    transpose16<true>(re, im, tr, g, t);
     key_wait(w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]);
     key_wait(w[8], w[9], w[10], w[11], w[12], w[13], w[14], w[15]);
 #pragma unroll
