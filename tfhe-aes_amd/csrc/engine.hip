@@ -383,14 +383,14 @@ static int launch_pbs(tfa_ctx *ctx, const uint32_t *in_base, uint32_t in_stride,
     }
     // Four mappings, picked by which finishes soonest on the device's CUs (measured time of one round of
     // workgroups over all CUs, microseconds, MI355X):
-    //   8 bootstraps per workgroup, two waves per SIMD (highest throughput)          11800 per 8 * CUs
-    //   4 bootstraps per workgroup, one wave per SIMD                                  8000 per 4 * CUs
+    //   8 bootstraps per workgroup, two waves per SIMD (highest throughput)          11000 per 8 * CUs
+    //   4 bootstraps per workgroup, one wave per SIMD                                  7600 per 4 * CUs
     //   one bootstrap spread over the 4 waves of a workgroup, one workgroup per CU    3000 per CUs
     //   the same with two workgroups per CU                                           5100 per 2 * CUs
     // A batch that fills whole rounds of the 8-wave kernel and leaves a short tail runs the tail separately.
     const uint64_t cus = ctx->n_cus;
     auto best_single = [&](uint64_t P, int &variant) -> uint64_t {
-        const uint64_t t8 = ((P + 8 * cus - 1) / (8 * cus)) * 11800, t4 = ((P + 4 * cus - 1) / (4 * cus)) * 8000;
+        const uint64_t t8 = ((P + 8 * cus - 1) / (8 * cus)) * 11000, t4 = ((P + 4 * cus - 1) / (4 * cus)) * 7600;
         const uint64_t lat_rest = P % (2 * cus), t_lat = (P / (2 * cus)) * 5100 + (lat_rest == 0 ? 0 : lat_rest <= cus ? 3000 : 5100);
         variant = t_lat <= t4 && t_lat <= t8 ? (P > cus ? 2 : 1) : (t8 < t4 ? 8 : 4);
         return variant == 8 ? t8 : variant == 4 ? t4 : t_lat;
@@ -417,7 +417,7 @@ static int launch_pbs(tfa_ctx *ctx, const uint32_t *in_base, uint32_t in_stride,
     const uint32_t full = (uint32_t)((n_jobs / (8 * cus)) * (8 * cus));
     if (ctx->force_waves) {
         launch(ctx->force_waves, 0, n_jobs);
-    } else if (full > 0 && full < n_jobs && (full / (8 * cus)) * 11800 + best_single(n_jobs - full, tail_variant) < t_single) {
+    } else if (full > 0 && full < n_jobs && (full / (8 * cus)) * 11000 + best_single(n_jobs - full, tail_variant) < t_single) {
         launch(8, 0, full);
         HIPCHK(ctx, hipGetLastError());
         launch(tail_variant, full, n_jobs - full);
