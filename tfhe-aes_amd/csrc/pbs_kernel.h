@@ -84,14 +84,16 @@ constexpr int kTwBytes = 4096;                   // per-lane twiddle table share
 #else
 #define TFA_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
+// Build switches of the bootstrap kernels.  The defaults are the measured best; the other settings are kept so that
+// the measurements can be repeated (tools/build_exp.sh builds a library per setting, tools/run_exp.sh times them).
 #ifndef TFA_PIN_GROUP4
-#define TFA_PIN_GROUP4 1
+#define TFA_PIN_GROUP4 1  // one wave per SIMD: the sums of a frequency group are pinned after the reduction (0: 7 % slower, 486 registers)
 #endif
 #ifndef TFA_PIN_GROUP
-#define TFA_PIN_GROUP 1
+#define TFA_PIN_GROUP 1  // two waves per SIMD: the same pin; without it two groups' partial sums overlap and 21 registers spill
 #endif
 #ifndef TFA_MAC_STAGGER
-#define TFA_MAC_STAGGER 1
+#define TFA_MAC_STAGGER 1  // two waves per SIMD: key columns in two pairs with counted waits (0: one wait per group, 6 % slower in quad mode)
 #endif
 #ifndef TFA_INV_TW_PREFETCH
 #define TFA_INV_TW_PREFETCH 0  // 8 waves: 1 = the inverse transform's twiddles are read before its first DFT16 (measured 4 % slower)
@@ -103,7 +105,7 @@ constexpr int kTwBytes = 4096;                   // per-lane twiddle table share
 #define TFA_FFT_PAIR 0  // 8 waves: 1 = the two forward transforms of a step share their twiddle reads (fewer LDS reads, measured 2.5 % slower)
 #endif
 #ifndef TFA_PIN_SPECTRA
-#define TFA_PIN_SPECTRA 1
+#define TFA_PIN_SPECTRA 1  // the forward transforms' outputs are pinned before the products (0: the compiler evaluates them lazily and spills)
 #endif
 #ifndef TFA_PBS8_PREFETCH
 #define TFA_PBS8_PREFETCH 1  // 8 waves: key words of the next frequency group are read while the previous group is reduced
