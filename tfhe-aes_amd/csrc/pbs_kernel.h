@@ -79,11 +79,6 @@ constexpr int kTwBytes = 4096;                   // per-lane twiddle table share
 #ifndef TFA_PBS8_BOTH
 #define TFA_PBS8_BOTH 1  // 0 builds the older 8-wave variant that reduces each level on its own (15 % slower)
 #endif
-#ifdef TFA_NO_SCHED_FENCE
-#define TFA_SCHED_FENCE() ((void)0)
-#else
-#define TFA_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#endif
 // Build switches of the bootstrap kernels.  The defaults are the measured best; the other settings are kept so that
 // the measurements can be repeated (tools/build_exp.sh builds a library per setting, tools/run_exp.sh times them).
 #ifndef TFA_PIN_GROUP4
