@@ -113,7 +113,8 @@ def aes_ctr_sharded(device, rank, world, coll_dev, blocks_per_gpu=8):
     states = [H.State.from_u8_enc(pts[b], keys) for b in mine]
     keys.flush()
     if world > 1:
-        dist.barrier()
+        import torch
+        dist.all_reduce(torch.zeros(1, device=coll_dev))  # barrier on the transport in use
     t = time.perf_counter()
     H.CTR(rk, counters, len(mine)).encrypt(states)
     keys.flush()
@@ -153,11 +154,24 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")  # "gloo" rehearses several ranks on one GPU
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            # one group with both transports: CUDA tensors travel over RCCL / xGMI, CPU tensors over gloo.  One probe
+            # collective, so that a broken fabric shows here and not after the timed steps; the timed path has no
+            # collective, so the gather and the barriers can fall back to gloo.
+            dist.init_process_group("cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+            try:
+                probe = torch.ones(1, device=torch.device("cuda", local_rank))
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                assert int(probe.item()) == world
+            except Exception as exc:
+                print(f"[bench] rank {rank}: RCCL unavailable ({exc!r}); collectives fall back to gloo", file=sys.stderr, flush=True)
+                backend = "gloo"
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    else:
+        backend = "none"
 
-    coll_dev = torch.device("cuda", local_rank) if os.environ.get("BENCH_DIST_BACKEND", "nccl") == "nccl" else torch.device("cpu")
+    coll_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     p = E.default_params()
     lwe_sk, glwe_sk, bsk, ksk = E.client_keygen(p, SEED)       # keys replicated: same seed on every rank
     ctx = E.Context(p, local_rank)
@@ -169,9 +183,12 @@ def main():
     even = np.arange(G) % 2 == 0
     gates = E.make_gates(np.where(even, E.NAND, E.XOR), np.arange(G), np.arange(G, 2 * G), None, np.arange(2 * G, 3 * G))
 
+    def dist_barrier():  # a collective on the transport in use (dist.barrier() would pick the CUDA one by itself)
+        dist.all_reduce(torch.zeros(1, device=coll_dev))
+
     def barrier():
         if world > 1:
-            dist.barrier()
+            dist_barrier()
         torch.cuda.synchronize()
         ctx.sync()
 
@@ -223,6 +240,7 @@ def main():
         }
         if gathered is not None:
             line["gathered_ciphertexts"] = int(gathered.shape[0] * gathered.shape[1])
+            line["collective_backend"] = "rccl" if backend == "nccl" else backend
     ctx.close()
     if not args.no_aes:
         # every rank takes part: 8 CTR blocks per GPU, max time over ranks
@@ -241,7 +259,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(p, lwe_sk, bsk, ksk)
         print(json.dumps(line), flush=True)
     if world > 1:
-        dist.barrier()
+        dist_barrier()
         dist.destroy_process_group()
 
 
