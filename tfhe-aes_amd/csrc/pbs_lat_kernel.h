@@ -19,6 +19,9 @@
 
 namespace tfa {
 
+#ifndef TFA_LAT_READ_ALL
+#define TFA_LAT_READ_ALL 0  // 1: one workgroup per CU reads all 24 foreign spectrum words before the first product (328 registers; measured 5 % slower)
+#endif
 #ifndef TFA_LAT_SPREAD_KEY
 #define TFA_LAT_SPREAD_KEY 1
 #endif
@@ -268,6 +271,35 @@ __global__ void __launch_bounds__(256, PER_CU)
 #ifndef TFA_EXP_NOBARRIER
         __syncthreads();
 #endif
+#if TFA_LAT_READ_ALL
+        if constexpr (PER_CU == 1) {
+            // one wave per SIMD may use 512 registers: all 24 reads of the other polynomials' spectra in flight at once
+            c64 fa[3][8];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int p = (w + 1 + k) & 3;
+#pragma unroll
+                for (int e = 0; e < 8; e++) fa[k][e] = sp[(p * 8 + e) * 64 + L];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+#pragma unroll
+                for (int pp = 0; pp < 4; pp++) {
+                    if (pp != ((w + 1 + k) & 3)) continue;
+#pragma unroll
+                    for (int lv = 0; lv < 2; lv++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const c64 b = key[lv][pp][q];
+                            our[0][q] += fa[k][lv * 4 + q].x * b.x - fa[k][lv * 4 + q].y * b.y;
+                            oui[0][q] += fa[k][lv * 4 + q].x * b.y + fa[k][lv * 4 + q].y * b.x;
+                        }
+                }
+            }
+        } else
+#endif
+        {
 #pragma unroll
         for (int p = 0; p < 4; p++) {
             if (p == w) continue;
@@ -287,6 +319,7 @@ __global__ void __launch_bounds__(256, PER_CU)
                     our[0][q] += f[lv * 4 + q].x * b.x - f[lv * 4 + q].y * b.y;
                     oui[0][q] += f[lv * 4 + q].x * b.y + f[lv * 4 + q].y * b.x;
                 }
+        }
         }
 #ifndef TFA_EXP_NOBARRIER
         if (LatGeom<PER_CU>::kSpecBuffers == 1) __syncthreads();
