@@ -184,6 +184,29 @@ def clear_gate(op, a, b, c):
                      [a & b, 1 - (a & b), a | b, 1 - (a | b), a ^ b, 1 - (a ^ b), np.where(a == 1, b, c)]).astype(np.uint8)
 
 
+def test_gates_match_the_committed_golden_fixture(gpu_ctx, oracle, okeys):
+    """tests/golden/tfhe_golden.json (eight gates of all kinds, made by tests/golden/make_golden.py with the exact
+    engine): the GPU's output ciphertexts hash to the committed value, word for word."""
+    import hashlib
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tfhe_golden.json")))
+    lwe_sk = okeys[0]
+    bits = np.array(gold["input_bits"], np.uint8).reshape(3, -1)
+    ins = [oracle.encrypt_bits(lwe_sk, gold["enc_seed"], s, bits[s]) for s in range(3)]  # inputs: the fixture's streams
+    assert hashlib.sha256(np.stack(ins).tobytes()).hexdigest() == gold["inputs_sha256"]
+    G = bits.shape[1]
+    gpu_ctx.pool_reserve(4 * G)
+    for k, ct in enumerate(ins):
+        gpu_ctx.pool_write(np.arange(k * G, (k + 1) * G), ct)
+    gpu_ctx.stage_submit(E.make_gates(np.array(gold["ops"]), np.arange(G), np.arange(G, 2 * G), np.arange(2 * G, 3 * G), np.arange(3 * G, 4 * G)))
+    gpu_ctx.sync()
+    out = gpu_ctx.pool_read(np.arange(3 * G, 4 * G))
+    assert [int(x) for x in out[:, -1]] == gold["output_bodies"]
+    assert hashlib.sha256(np.ascontiguousarray(out).tobytes()).hexdigest() == gold["outputs_sha256"]
+    assert list(E.client_decrypt(E.default_params(), lwe_sk, out)) == gold["output_bits"]
+
+
 def test_mixed_gates_with_negations(gpu_ctx, oracle, okeys, obsk_f):
     lwe_sk, _, bsk, ksk = okeys
     G = 2048
