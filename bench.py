@@ -46,7 +46,7 @@ def measured_traffic():
         return None
 
 
-def cpu_baseline(p, lwe_sk, bsk, ksk, budget_s=12.0):
+def cpu_baseline(p, lwe_sk, bsk, ksk, budget_s=20.0):
     from oracle.pyoracle import NAND, XOR, Oracle
     o = Oracle()
     threads = o.num_threads()
