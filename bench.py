@@ -166,6 +166,11 @@ def main():
             except Exception as exc:
                 print(f"[bench] rank {rank}: RCCL unavailable ({exc!r}); collectives fall back to gloo", file=sys.stderr, flush=True)
                 backend = "gloo"
+            # every rank takes the same transport: one failed probe moves all of them to gloo
+            ok = torch.tensor([1 if backend == "nccl" else 0], dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                backend = "gloo"
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     else:

@@ -82,6 +82,14 @@ __global__ void __launch_bounds__(256) k_rate(double* out, int iters) {
         u0 = (unsigned)__builtin_amdgcn_update_dpp((int)u0, (int)u0, 0x4E, 0xF, 0xF, false); u1 = (unsigned)__builtin_amdgcn_update_dpp((int)u1, (int)u1, 0xB1, 0xF, 0xF, false);
         u2 = (unsigned)__builtin_amdgcn_update_dpp((int)u2, (int)u2, 0x4E, 0xF, 0xF, false); u3 = (unsigned)__builtin_amdgcn_update_dpp((int)u3, (int)u3, 0xB1, 0xF, 0xF, false);
       }
+    } else if (MODE == 12) {  // v_cvt_f64_i32
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        asm volatile("" : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3));
+        x0 = (double)(int)u0; x1 = (double)(int)u1; x2 = (double)(int)u2; x3 = (double)(int)u3;
+        x4 = (double)(int)(u0 ^ 1); x5 = (double)(int)(u1 ^ 1); x6 = (double)(int)(u2 ^ 1); x7 = (double)(int)(u3 ^ 1);
+        asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+      }
     } else if (MODE == 4) {  // v_mul_lo_u32
 #pragma unroll
       for (int j = 0; j < 16; j++) { u0 = u0 * u1 + 1; u1 = u1 * u2 + 1; u2 = u2 * u3 + 1; u3 = u3 * u0 + 1; }
@@ -125,6 +133,7 @@ int main() {
     rate<2>("permlane_swap", 64, blocks, th); rate<4>("mul_lo_u32", 64, blocks, th); rate<5>("mix_fma_int", 128, blocks, th);
     rate<6>("dot4_i8", 64, blocks, th); rate<7>("int_add_xor", 64, blocks, th);
     rate<8>("fma_f64_vvv", 64, blocks, th); rate<9>("add_f64_vv", 64, blocks, th); rate<10>("fma_f64_svv", 64, blocks, th); rate<11>("dpp_quad_mov", 64, blocks, th);
+    rate<12>("cvt_f64_i32+xor/2", 64, blocks, th);
   }
   return 0;
 }
