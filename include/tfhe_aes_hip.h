@@ -76,7 +76,10 @@ int tfa_pool_device_ptr(tfa_ctx *ctx, void **dptr, uint32_t *stride_words, uint3
 /* The per-stage batch submitter: replaces the rayon pool of FHEByte::sub_byte
  * (/root/reference/base/src/primitive.rs:250-265, Runnable::run boolean_tree.rs:644-654) and the
  * per-bit loops of FHEByte::{xor,and,or}_in_place / mul_x_gf2_in_place (primitive.rs:96-133,
- * 349-362).  Asynchronous and ordered on the context's stream. */
+ * 349-362).  Asynchronous and ordered on the context's stream.  Every gate reads the pool as it was
+ * before the stage: a bootstrapped gate may write a slot that it or any other gate of the stage reads
+ * (the *_assign forms); a NOT/COPY may write its own input slot, but not one that another NOT/COPY of
+ * the same stage reads, and two gates of a stage must not write the same slot. */
 int tfa_stage_submit(tfa_ctx *ctx, const tfa_gate *gates, uint32_t count);
 int tfa_sync(tfa_ctx *ctx);
 

@@ -252,6 +252,25 @@ def test_not_copy_and_chained_stages(gpu_ctx, oracle, okeys):
     assert (raw[1] == (0 - raw[0].astype(np.int64)) % 2**32).all()  # NOT is an exact LWE negation
 
 
+def test_in_place_gates_read_the_pool_as_it_was_before_the_stage(gpu_ctx, oracle, okeys):
+    """The *_assign forms (primitive.rs:96-133: xor_assign / and_assign / or_assign on the left operand): a gate may
+    write a slot that it or another gate of the same stage reads; all of them see the value from before the stage."""
+    lwe_sk = okeys[0]
+    bits = np.array([1, 0, 1, 1, 0, 1], np.uint8)
+    gpu_ctx.pool_reserve(32)
+    gpu_ctx.pool_write(np.arange(6), oracle.encrypt_bits(lwe_sk, 83, 0, bits))
+    g = E.make_gates([E.XOR, E.AND, E.OR, E.MUX, E.NOT, E.COPY],
+                     [0, 0, 2, 3, 5, 1],       # in0 (MUX: selector)
+                     [1, 1, 0, 0, 0, 0],       # in1
+                     [0, 0, 0, 4, 0, 0],       # in2
+                     [0, 1, 2, 3, 5, 10])      # out: gates 0-3 overwrite operands that later gates of the stage read
+    gpu_ctx.stage_submit(g)
+    gpu_ctx.sync()
+    got = oracle.decrypt_bits(lwe_sk, gpu_ctx.pool_read([0, 1, 2, 3, 5, 10]))
+    b = bits
+    assert list(got) == [b[0] ^ b[1], b[0] & b[1], b[2] | b[0], (b[0] if b[3] else b[4]), 1 - b[5], b[1]]
+
+
 def test_error_paths(gpu_ctx, okeys):
     lib = E.load_library()
     fresh = E.Context(E.default_params(), 0)

@@ -553,13 +553,15 @@ extern "C" int tfa_stage_submit(tfa_ctx *ctx, const tfa_gate *gates, uint32_t co
     HIPCHK(ctx, hipEventRecord(ctx->h_stage_ev[slot], ctx->stream));
     rc = launch_pbs(ctx, ctx->d_pool, ctx->pool_stride, reinterpret_cast<const PbsJob *>(ctx->d_jobs), n_pbs, ctx->p.lwe_dimension, nullptr);
     if (rc) return rc;
-    rc = launch_ks(ctx, reinterpret_cast<const KsJob *>(ctx->d_jobs + off_ks), n_ks, ctx->d_pool, ctx->pool_stride);
-    if (rc) return rc;
+    // NOT/COPY before the keyswitch, the only writer of bootstrapped results: every gate of the stage, linear ones
+    // included, reads the pool as it was before the stage, so a gate may write the slot it (or another gate) reads.
     if (n_lin) {
         hipLaunchKernelGGL(lin_kernel, dim3(n_lin), dim3(256), 0, ctx->stream, ctx->d_pool, ctx->pool_stride,
                            reinterpret_cast<const LinJob *>(ctx->d_jobs + off_lin), n_lin, ctx->p.lwe_dimension);
         HIPCHK(ctx, hipGetLastError());
     }
+    rc = launch_ks(ctx, reinterpret_cast<const KsJob *>(ctx->d_jobs + off_ks), n_ks, ctx->d_pool, ctx->pool_stride);
+    if (rc) return rc;
     ctx->stats.gate_count += count;
     ctx->stats.stage_count++;
     return TFA_OK;
