@@ -271,6 +271,32 @@ def test_in_place_gates_read_the_pool_as_it_was_before_the_stage(gpu_ctx, oracle
     assert list(got) == [b[0] ^ b[1], b[0] & b[1], b[2] | b[0], (b[0] if b[3] else b[4]), 1 - b[5], b[1]]
 
 
+def test_two_contexts_with_different_keys_run_interleaved(gpu_ctx, oracle, okeys):
+    """Two contexts on one GPU (a caller serving two key sets): submits interleave on their own streams and no state
+    is shared, so each decrypts under its own key only."""
+    other_keys = oracle.keygen(0x5446484541455321 + 17)
+    other = E.Context(E.default_params(), 0)
+    try:
+        other.keys_upload(other_keys[2], other_keys[3])
+        rng = np.random.default_rng(5)
+        n = 300  # a width that takes the two-workgroups-per-CU mapping
+        expect, ctxs = [], [(gpu_ctx, okeys[0]), (other, other_keys[0])]
+        for seed, (c, sk) in enumerate(ctxs):
+            bits = rng.integers(0, 2, 2 * n).astype(np.uint8)
+            c.pool_reserve(3 * n)
+            c.pool_write(np.arange(2 * n), oracle.encrypt_bits(sk, 90 + seed, 0, bits))
+            expect.append(bits[:n] & bits[n:])
+        gates = E.make_gates(np.full(n, E.AND), np.arange(n), np.arange(n, 2 * n), None, np.arange(2 * n, 3 * n))
+        for _ in range(2):  # both streams busy at once, twice (the second pass overwrites with the same results)
+            for c, _sk in ctxs:
+                c.stage_submit(gates)
+        for (c, sk), exp in zip(ctxs, expect):
+            c.sync()
+            assert (oracle.decrypt_bits(sk, c.pool_read(np.arange(2 * n, 3 * n))) == exp).all()
+    finally:
+        other.close()
+
+
 def test_error_paths(gpu_ctx, okeys):
     lib = E.load_library()
     fresh = E.Context(E.default_params(), 0)
