@@ -154,6 +154,33 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// A fixed fp64 value written into a scalar register pair right where it is used.  Left to itself the compiler loads
+// every constant of the step loop once, ahead of the loop; the folded transforms have more of them than there are scalar
+// registers, and the surplus is parked in vector-register lanes and fetched back with v_readlane at every use.
+#ifndef TFA_SCONST
+#define TFA_SCONST 0
+#endif
+template <uint64_t BITS>
+__device__ __forceinline__ double sconst() {
+    uint32_t lo, hi;
+    asm volatile("s_mov_b32 %0, %2\n\ts_mov_b32 %1, %3" : "=s"(lo), "=s"(hi) : "i"((uint32_t)BITS), "i"((uint32_t)(BITS >> 32)));
+    return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+#if TFA_SCONST
+#define TFA_K(x) sconst<__builtin_bit_cast(uint64_t, (double)(x))>()
+#else
+#define TFA_K(x) (x)
+#endif
+
 // ---- register DFT16 --------------------------------------------------------------------------
 // S = +1: kernel e^{+2 pi i nk/16}; S = -1: its conjugate.
 template <int S>
@@ -238,11 +265,11 @@ __device__ __forceinline__ void rot_tan(double &r, double &i, double tau) {  // 
     r = nr;
     i = ni;
 }
-// DFT4 of x0, c1 u1, c2 u2, c3 u3 (x0 unscaled), results in place
+// DFT4 of x0, c1 u1, c2 u2, c3 u3 (x0 unscaled), results in place; q = c3 / c1
 template <int S>
 __device__ __forceinline__ void dft4_scaled(double &r0, double &i0, double &r1, double &i1, double c1, double &r2, double &i2, double c2, double &r3,
-                                            double &i3, double c3) {
-    const double q = c3 / c1, sc = S > 0 ? c1 : -c1;
+                                            double &i3, double q) {
+    const double sc = S > 0 ? c1 : -c1;
     const double t0r = __builtin_fma(c2, r2, r0), t0i = __builtin_fma(c2, i2, i0), t1r = __builtin_fma(-c2, r2, r0), t1i = __builtin_fma(-c2, i2, i0);
     const double t2r = __builtin_fma(q, r3, r1), t2i = __builtin_fma(q, i3, i1), dr = __builtin_fma(-q, r3, r1), di = __builtin_fma(-q, i3, i1);
     r0 = __builtin_fma(c1, t2r, t0r);
@@ -257,10 +284,10 @@ __device__ __forceinline__ void dft4_scaled(double &r0, double &i0, double &r1, 
 // the same with x0 = c0 u0 scaled as well
 template <int S>
 __device__ __forceinline__ void dft4_allscaled(double &r0, double &i0, double c0, double &r1, double &i1, double c1, double &r2, double &i2, double c2,
-                                               double &r3, double &i3, double c3) {
+                                               double &r3, double &i3, double q) {
     r0 *= c0;
     i0 *= c0;
-    dft4_scaled<S>(r0, i0, r1, i1, c1, r2, i2, c2, r3, i3, c3);
+    dft4_scaled<S>(r0, i0, r1, i1, c1, r2, i2, c2, r3, i3, q);
 }
 // TWIST (forward transforms only, S = +1): the inputs are first multiplied by e^{i pi n / 32}
 template <int S, bool TWIST>
@@ -268,28 +295,29 @@ __device__ __forceinline__ void dft16m(double (&re)[16], double (&im)[16]) {
     constexpr double C1 = 0.9238795325112867, S1 = 0.3826834323650898, R = 0.7071067811865476;
     constexpr double T1 = S1 / C1, T3 = C1 / S1;  // tan(pi/8), tan(3 pi/8)
     static_assert(!TWIST || S > 0, "the twist belongs to the forward transform");
-#pragma unroll
-    for (int n2 = 0; n2 < 4; n2++) {
+    static_for<4>([&](auto N2) __attribute__((always_inline)) {
+        constexpr int n2 = N2.value;
         if constexpr (!TWIST) {
             dft4<S>(re[n2], im[n2], re[4 + n2], im[4 + n2], re[8 + n2], im[8 + n2], re[12 + n2], im[12 + n2]);
         } else {
-#pragma unroll
-            for (int a = 0; a < 4; a++)
-                if (n2 + 4 * a > 0) rot_tan<1>(re[n2 + 4 * a], im[n2 + 4 * a], kS32[n2 + 4 * a] / kC32[n2 + 4 * a]);
-            if (n2 == 0)
-                dft4_scaled<1>(re[0], im[0], re[4], im[4], kC32[4], re[8], im[8], kC32[8], re[12], im[12], kC32[12]);
+            static_for<4>([&](auto A) __attribute__((always_inline)) {
+                constexpr int n = n2 + 4 * A.value;
+                if constexpr (n > 0) rot_tan<1>(re[n], im[n], TFA_K(kS32[n] / kC32[n]));
+            });
+            if constexpr (n2 == 0)
+                dft4_scaled<1>(re[0], im[0], re[4], im[4], TFA_K(kC32[4]), re[8], im[8], TFA_K(kC32[8]), re[12], im[12], TFA_K(kC32[12] / kC32[4]));
             else
-                dft4_allscaled<1>(re[n2], im[n2], kC32[n2], re[4 + n2], im[4 + n2], kC32[4 + n2], re[8 + n2], im[8 + n2], kC32[8 + n2], re[12 + n2],
-                                  im[12 + n2], kC32[12 + n2]);
+                dft4_allscaled<1>(re[n2], im[n2], TFA_K(kC32[n2]), re[4 + n2], im[4 + n2], TFA_K(kC32[4 + n2]), re[8 + n2], im[8 + n2],
+                                  TFA_K(kC32[8 + n2]), re[12 + n2], im[12 + n2], TFA_K(kC32[12 + n2] / kC32[4 + n2]));
         }
-    }
+    });
     // position 4*k1 + n2 now holds u[n2][k1]; the twiddles W16^(n2*k1) = c (1 + i S tau) go into the second layer
     dft4<S>(re[0], im[0], re[1], im[1], re[2], im[2], re[3], im[3]);
     // k1 = 1: e = 1, 2, 3
-    rot_tan<S>(re[5], im[5], T1);
+    rot_tan<S>(re[5], im[5], TFA_K(T1));
     rot_tan<S>(re[6], im[6], 1.0);
-    rot_tan<S>(re[7], im[7], T3);
-    dft4_scaled<S>(re[4], im[4], re[5], im[5], C1, re[6], im[6], R, re[7], im[7], S1);
+    rot_tan<S>(re[7], im[7], TFA_K(T3));
+    dft4_scaled<S>(re[4], im[4], re[5], im[5], TFA_K(C1), re[6], im[6], TFA_K(R), re[7], im[7], TFA_K(S1 / C1));
     // k1 = 2: e = 2, 4 (times S i: a rotation by a quarter turn, no arithmetic), 6
     rot_tan<S>(re[9], im[9], 1.0);
     {
@@ -298,12 +326,12 @@ __device__ __forceinline__ void dft16m(double (&re)[16], double (&im)[16]) {
         im[10] = S > 0 ? r : -r;
     }
     rot_tan<S>(re[11], im[11], -1.0);
-    dft4_scaled<S>(re[8], im[8], re[9], im[9], R, re[10], im[10], 1.0, re[11], im[11], -R);
+    dft4_scaled<S>(re[8], im[8], re[9], im[9], TFA_K(R), re[10], im[10], 1.0, re[11], im[11], -1.0);
     // k1 = 3: e = 3, 6, 9
-    rot_tan<S>(re[13], im[13], T3);
+    rot_tan<S>(re[13], im[13], TFA_K(T3));
     rot_tan<S>(re[14], im[14], -1.0);
-    rot_tan<S>(re[15], im[15], T1);
-    dft4_scaled<S>(re[12], im[12], re[13], im[13], S1, re[14], im[14], -R, re[15], im[15], -C1);
+    rot_tan<S>(re[15], im[15], TFA_K(T1));
+    dft4_scaled<S>(re[12], im[12], re[13], im[13], TFA_K(S1), re[14], im[14], TFA_K(-R), re[15], im[15], TFA_K(-C1 / S1));
     // position 4*k1 + k2 holds X[k1 + 4*k2]: undo the digit reversal (register renaming only)
     double tr[16], ti[16];
 #pragma unroll
@@ -322,6 +350,9 @@ __device__ __forceinline__ void dft16m(double (&re)[16], double (&im)[16]) {
 // All forms give the same values to rounding; measured on the 8-wave kernel the folded forms issue up to 120 fewer fp64
 // instructions per step but make the compiler serialise the LDS reads of the step (one read, one wait), which costs
 // more than the instructions save (mask 7: 167 k against 187 k bootstraps/s; mask 15 also spills 170 scalar registers).
+// With the constants written into scalar registers where they are used (TFA_SCONST=1) nothing spills and the kernel
+// needs 234 vector registers, and it is still slower (masks 8 / 7 / 15: 182 k / 178 k / 176 k against 188 k): a fused
+// multiply-add with a scalar operand issues in 4.8-5.2 clocks, the additions it replaces in 4.2.
 #ifndef TFA_FMA_DFT
 #define TFA_FMA_DFT 0
 #endif
@@ -598,14 +629,6 @@ __device__ __forceinline__ void key_wait_four(v2d &a, v2d &b, v2d &c, v2d &d) {
         asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
     else
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
-}
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F &f, std::integer_sequence<int, I...>) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-    static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
 // Inverse transform whose sixteen twiddles are read (pinned, uncounted by the compiler) before the first register
