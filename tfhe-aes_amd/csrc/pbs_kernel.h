@@ -351,8 +351,9 @@ __device__ __forceinline__ void dft16m(double (&re)[16], double (&im)[16]) {
 // instructions per step but make the compiler serialise the LDS reads of the step (one read, one wait), which costs
 // more than the instructions save (mask 7: 167 k against 187 k bootstraps/s; mask 15 also spills 170 scalar registers).
 // With the constants written into scalar registers where they are used (TFA_SCONST=1) nothing spills and the kernel
-// needs 234 vector registers, and it is still slower (masks 8 / 7 / 15: 182 k / 178 k / 176 k against 188 k): a fused
-// multiply-add with a scalar operand issues in 4.8-5.2 clocks, the additions it replaces in 4.2.
+// needs 234 vector registers, and it is still slower (masks 8 / 7 / 15: 182 k / 178 k / 176 k against 188 k).  The
+// multiply-adds themselves issue as fast as additions (4.2-4.4 clocks either way in tools/probe.hip), so the loss is in
+// the schedule of the longer dependent chains, not in the instruction count.
 #ifndef TFA_FMA_DFT
 #define TFA_FMA_DFT 0
 #endif
