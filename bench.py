@@ -90,8 +90,9 @@ def aes_block(device):
     after = keys.host_stats()
     ok = state.decrypt_to_u8().hex() == "3925841d02dc09fbdc118597196a0b32"
     keys.close()
-    return {"ecb_encrypt_block_s": round(dt, 4), "correct": ok, "stages": after["stages"] - before["stages"],
-            "gates": after["gates"] - before["gates"], "pbs": 127872}
+    stages = after["stages"] - before["stages"]
+    return {"ecb_encrypt_block_s": round(dt, 4), "correct": ok, "stages": stages, "gates": after["gates"] - before["gates"], "pbs": 127872,
+            "mean_stage_width_pbs": round(127872 / max(1, stages), 1)}
 
 
 def aes_ctr_sharded(device, rank, world, coll_dev, blocks_per_gpu=8):
