@@ -5,18 +5,28 @@ input ciphertexts already sit in the device pool.  With --gpus N every rank runs
 its own GPU with replicated keys (weak scaling, no collective in the data path); the only exchange
 is a gather of output ciphertexts after the timed region.
 
+Launching: `python bench.py --gpus N` with no WORLD_SIZE in the environment starts the N ranks itself
+(child processes, spawned before anything touches the GPU, rendezvous on 127.0.0.1); under
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it is one of the ranks.  The
+collectives run on RCCL; a failed RCCL probe ends the run with a non-zero exit.  BENCH_DIST_BACKEND=gloo
+is the explicit switch for rehearsing several ranks on one GPU.
+
 Prints one JSON line: metric/value per the driver contract, plus
   roofline     - achieved fp64 FLOP/s of the blind-rotation kernel (algorithmic flop per launch /
                  mean kernel time from HIP events on the engine's stream) against the fp64 peak
   cpu_baseline - the CPU oracle (C restatement, fp64 FFT engine, OpenMP over gates) on a bounded
                  sample of the same workload, timed on this node's host cores (rank 0, N=1 only)
-  aes          - seconds for one homomorphic AES-128 ECB block (FIPS-197 App. B, latency), and the
-                 sharded case: 8 independent CTR blocks per GPU (SP 800-38A F.5.1 extended), keys
-                 replicated, outputs gathered over the process group; both checked against the standard
+  aes          - the AES configurations of BASELINE.json on the same engine, each checked against
+                 FIPS-197 / SP 800-38A (tests/golden/aes_vectors.json): one ECB block encrypt and decrypt
+                 (configs[2]), online key expansion and the 4-block CBC and OFB chains (configs[3]; N=1 only:
+                 sequential chains do not shard), and 8 independent CTR blocks per GPU, block b on rank
+                 b mod N, outputs all-gathered on the device (configs[4]: 64 blocks on 8 GPUs)
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,19 +41,22 @@ GATES_PER_STEP = 65536
 FLOP_PER_PBS = 805 * 206848          # 12 FFT-256 + 12 twists + 32 complex vector MACs per blind-rotation step
 FP64_PEAK_TFLOPS = 78.6              # MI355X fp64 vector = matrix peak (datasheet)
 SEED = 0x5446484541455321
+PMC_SUMMARIES = ("r2_pmc_summary.json", "r1_pmc_summary.json")   # newest first
 
 
 def measured_traffic():
     """HBM bytes per 65536-bootstrap launch of the dominant kernel from the committed rocprofv3 PMC passes
     (FETCH_SIZE doubled as gfx950 requires for 16-byte-per-lane reads, plus WRITE_SIZE; both in KiB).  Counters
-    cannot be collected inside a timed run, so this is the profile's number, or None without the file."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r1_pmc_summary.json")) as f:
-            cur = json.load(f)["counters_current_kernels"]
-        c = next(v for k, v in cur.items() if k.startswith("tfa::pbs_kernel<8"))
-        return int((2 * c["FETCH_SIZE@65536"] + c["WRITE_SIZE@65536"]) * 1024)
-    except (OSError, KeyError, ValueError, StopIteration):
-        return None
+    cannot be collected inside a timed run, so this is the newest profile's number (with its file name), or None."""
+    for name in PMC_SUMMARIES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                cur = json.load(f)["counters_current_kernels"]
+            c = next(v for k, v in cur.items() if k.startswith("tfa::pbs_kernel<8"))
+            return int((2 * c["FETCH_SIZE@65536"] + c["WRITE_SIZE@65536"]) * 1024), name
+        except (OSError, KeyError, ValueError, StopIteration):
+            continue
+    return None, None
 
 
 def cpu_baseline(p, lwe_sk, bsk, ksk, budget_s=20.0):
@@ -71,64 +84,190 @@ def cpu_baseline(p, lwe_sk, bsk, ksk, budget_s=20.0):
             "sample": f"{count} of the {GATES_PER_STEP} NAND/XOR gates, oracle fp64-FFT engine, OpenMP over gates, {dt:.1f} s"}
 
 
-def aes_block(device):
-    """One FIPS-197 Appendix B block through the host mirror (offline round keys), encrypt only timed."""
+def golden():
+    with open(os.path.join(ROOT, "tests", "golden", "aes_vectors.json")) as f:
+        return json.load(f)
+
+
+class Leg:
+    """Times one AES leg on the host mirror: wall seconds around the recorded gates' execution, plus the stages,
+    gates and bootstraps the engine ran for it."""
+
+    def __init__(self, keys):
+        self.keys = keys
+
+    def __enter__(self):
+        self.keys.flush()
+        self.h0, self.e0 = self.keys.host_stats(), self.keys.engine_stats()
+        self.t0 = time.perf_counter()
+        return self
+
+    def __exit__(self, *exc):
+        self.keys.flush()
+        self.seconds = time.perf_counter() - self.t0
+        h1, e1 = self.keys.host_stats(), self.keys.engine_stats()
+        self.stages = h1["stages"] - self.h0["stages"]
+        self.gates = h1["gates"] - self.h0["gates"]
+        self.pbs = int(e1.pbs_count - self.e0.pbs_count)
+
+    def fields(self, prefix):
+        return {f"{prefix}_s": round(self.seconds, 4), f"{prefix}_stages": self.stages, f"{prefix}_pbs": self.pbs,
+                f"{prefix}_mean_stage_width_pbs": round(self.pbs / max(1, self.stages), 1)}
+
+
+def aes_single_gpu(device):
+    """BASELINE configs[2] and configs[3] on one GPU, every result checked against the standards' vectors."""
     from tfhe_aes_amd import host as H
+    g = golden()
+    fb, sp = g["fips197_b"], g["sp800_38a"]
     keys = H.gen_keys(SEED ^ 0x77, device)
-    key = bytes.fromhex("2b7e151628aed2a6abf7158809cf4f3c")
-    rk = [H.Key.from_u8_enc(k, keys) for k in H.key_expansion_clear(key)]
+    out = {}
+    key = bytes.fromhex(fb["key"])
+    clear_rk = H.key_expansion_clear(key)
+    rk = [H.Key.from_u8_enc(k, keys) for k in clear_rk]            # offline expansion: round keys encrypted by the client
     ecb = H.ECB(rk)
-    state = H.State.from_u8_enc(bytes.fromhex("3243f6a8885a308d313198a2e0370734"), keys)
-    warm = state.clone()
+    warm = H.State.from_u8_enc(bytes(16), keys)
     warm.sub_bytes()
     keys.flush()
-    before = keys.host_stats()
-    t = time.perf_counter()
-    ecb.encrypt(state)
-    keys.flush()
-    dt = time.perf_counter() - t
-    after = keys.host_stats()
-    ok = state.decrypt_to_u8().hex() == "3925841d02dc09fbdc118597196a0b32"
+    # configs[2]: FIPS-197 Appendix B block, encrypt then decrypt (ecb.rs:16-50)
+    state = H.State.from_u8_enc(bytes.fromhex(fb["plaintext"]), keys)
+    with Leg(keys) as leg:
+        ecb.encrypt(state)
+    ok_enc = state.decrypt_to_u8().hex() == fb["ciphertext"]
+    out.update(leg.fields("ecb_encrypt_block"))
+    out.update({"correct": ok_enc, "stages": leg.stages, "gates": leg.gates, "pbs": leg.pbs,
+                "mean_stage_width_pbs": round(leg.pbs / max(1, leg.stages), 1)})
+    with Leg(keys) as leg:
+        ecb.decrypt(state)
+    out.update(leg.fields("ecb_decrypt_block"))
+    out["ecb_decrypt_correct"] = state.decrypt_to_u8().hex() == fb["plaintext"]
+    # configs[3]: online key expansion (key_schedule.rs:162-171), then 4-block CBC and OFB chains (cbc.rs:22-31, ofb.rs:22-38)
+    k0 = H.Key.from_u8_enc(bytes.fromhex(sp["key"]), keys)
+    with Leg(keys) as leg:
+        online = k0.generate_round_keys()
+    out.update(leg.fields("key_expansion_online"))
+    out["key_expansion_online_correct"] = [k.decrypt_to_u8() for k in online] == H.key_expansion_clear(bytes.fromhex(sp["key"]))
+    iv = H.State.from_u8_enc(bytes.fromhex(sp["iv"]), keys)
+    pts = [bytes.fromhex(x) for x in sp["plaintext"]]
+    states = [H.State.from_u8_enc(x, keys) for x in pts]
+    with Leg(keys) as leg:
+        H.CBC(online, iv, 4).encrypt(states)
+    out.update(leg.fields("cbc4_encrypt"))
+    out["cbc4_correct"] = [s.decrypt_to_u8().hex() for s in states] == sp["cbc"]
+    states = [H.State.from_u8_enc(x, keys) for x in pts]
+    with Leg(keys) as leg:
+        H.OFB(online, iv, 4).encrypt(states)
+    out.update(leg.fields("ofb4"))
+    out["ofb4_correct"] = [s.decrypt_to_u8().hex() for s in states] == sp["ofb"]
     keys.close()
-    stages = after["stages"] - before["stages"]
-    return {"ecb_encrypt_block_s": round(dt, 4), "correct": ok, "stages": stages, "gates": after["gates"] - before["gates"], "pbs": 127872,
-            "mean_stage_width_pbs": round(127872 / max(1, stages), 1)}
+    return out
 
 
-def aes_ctr_sharded(device, rank, world, coll_dev, blocks_per_gpu=8):
-    """blocks_per_gpu * world independent CTR blocks, block b on rank b mod world (BASELINE configs[4] shape).
-    Returns (seconds for this rank's shard, gathered output ciphertexts or None)."""
+def aes_ctr_sharded(device, rank, world, on_device, blocks_per_gpu=8):
+    """blocks_per_gpu * world independent CTR blocks, block b on rank b mod world (BASELINE configs[4]: 64 blocks on
+    8 GPUs).  The outputs are all-gathered: on the device (RCCL) when `on_device`, through host tensors (gloo) otherwise.
+    Returns (seconds for this rank's shard, blocks, every gathered block correct against a clear AES / the standard)."""
+    import torch
     import torch.distributed as dist
     from tfhe_aes_amd import host as H
     from tfhe_aes_amd import shard
+    sp = golden()["sp800_38a"]
     n_blocks = blocks_per_gpu * world
     keys = H.gen_keys(SEED ^ 0x99, device)                     # same seed everywhere: replicated key material
-    rk = [H.Key.from_u8_enc(k, keys) for k in H.key_expansion_clear(bytes.fromhex("2b7e151628aed2a6abf7158809cf4f3c"))]
-    ctr0 = int("f0f1f2f3f4f5f6f7f8f9fafbfcfdfeff", 16)
-    nist_pt = ["6bc1bee22e409f96e93d7e117393172a", "ae2d8a571e03ac9c9eb76fac45af8e51", "30c81c46a35ce411e5fbc1191a0a52ef",
-               "f69f2445df4f9b17ad2b417be66c3710"]
+    key = bytes.fromhex(sp["key"])
+    rk = [H.Key.from_u8_enc(k, keys) for k in H.key_expansion_clear(key)]
+    ctr0 = int(sp["ctr_init"], 16)
     rng = np.random.default_rng(4242)
-    pts = [bytes.fromhex(nist_pt[b]) if b < 4 else rng.integers(0, 256, 16, dtype=np.uint8).tobytes() for b in range(n_blocks)]
+    pts = [bytes.fromhex(sp["plaintext"][b]) if b < 4 else rng.integers(0, 256, 16, dtype=np.uint8).tobytes() for b in range(n_blocks)]
     mine = shard.block_partition(n_blocks, world, rank)
     counters = [H.State.from_u128_enc((ctr0 + b) % (1 << 128), keys) for b in mine]
     states = [H.State.from_u8_enc(pts[b], keys) for b in mine]
     keys.flush()
     if world > 1:
-        import torch
-        dist.all_reduce(torch.zeros(1, device=coll_dev))  # barrier on the transport in use
+        dist.barrier()
     t = time.perf_counter()
     H.CTR(rk, counters, len(mine)).encrypt(states)
     keys.flush()
     dt = time.perf_counter() - t
-    local = np.stack([st.read() for st in states])
-    out = shard.gather_blocks(local, n_blocks, device=coll_dev) if world > 1 else local
+    words = keys.params.lwe_dimension + 1
+    if on_device:
+        local = torch.empty((len(mine), 128, words), dtype=torch.int32, device=torch.device("cuda", device))
+        H.read_states_device(states, local)
+        allb = shard.gather_blocks_device(local, n_blocks) if world > 1 else local
+        torch.cuda.synchronize()
+        out = allb.cpu().numpy().view(np.uint32) if rank == 0 else None
+    else:
+        local = np.stack([st.read() for st in states])
+        out = shard.gather_blocks(local, n_blocks) if world > 1 else local
     ok = None
     if rank == 0:
-        nist_ct = ["874d6191b620e3261bef6864990db6ce", "9806f66b7970fdff8617187bb9fffdff", "5ae4df3edbd5d35e5b4f09020db03eab",
-                   "1e031dda2fbe03d1792170a0f3009cee"]
-        ok = all(H.State.import_lwe(out[b], keys).decrypt_to_u8().hex() == nist_ct[b] for b in range(4))
+        got = [H.State.import_lwe(out[b], keys).decrypt_to_u8() for b in range(n_blocks)]
+        crk = H.key_expansion_clear(key)
+        exp = [bytes(x ^ y for x, y in zip(aes128_encrypt_block(crk, ((ctr0 + b) % (1 << 128)).to_bytes(16, "big")), pts[b])) for b in range(n_blocks)]
+        ok = got == exp and [x.hex() for x in got[:4]] == sp["ctr"]
     keys.close()
     return dt, n_blocks, ok
+
+
+def _aes_sbox():
+    """The AES S-box from its definition (inverse in GF(2^8) followed by the affine map), for the clear check below."""
+    def mul(a, b):
+        r = 0
+        for _ in range(8):
+            if b & 1:
+                r ^= a
+            a = ((a << 1) ^ 0x11B) if a & 0x80 else (a << 1)
+            b >>= 1
+        return r
+    box = []
+    for x in range(256):
+        inv = next((y for y in range(1, 256) if mul(x, y) == 1), 0)
+        box.append(inv ^ ((inv << 1 | inv >> 7) & 0xFF) ^ ((inv << 2 | inv >> 6) & 0xFF) ^ ((inv << 3 | inv >> 5) & 0xFF) ^ ((inv << 4 | inv >> 4) & 0xFF) ^ 0x63)
+    return box
+
+
+def aes128_encrypt_block(round_keys, block):
+    """Clear AES-128 of one block from the 11 expanded round keys (FIPS-197), column-major state as in the standard."""
+    box = _aes_sbox() if not hasattr(aes128_encrypt_block, "box") else aes128_encrypt_block.box
+    aes128_encrypt_block.box = box
+    xt = lambda a: ((a << 1) ^ 0x1B) & 0xFF if a & 0x80 else a << 1
+    s = [b ^ k for b, k in zip(block, round_keys[0])]
+    for rnd in range(1, 11):
+        s = [box[b] for b in s]
+        s = [s[(i + 4 * (i % 4)) % 16] for i in range(16)]                       # ShiftRows on s[4 c + r]
+        if rnd < 10:
+            m = []
+            for c in range(4):
+                a = s[4 * c:4 * c + 4]
+                m += [xt(a[i]) ^ xt(a[(i + 1) % 4]) ^ a[(i + 1) % 4] ^ a[(i + 2) % 4] ^ a[(i + 3) % 4] for i in range(4)]
+            s = m
+        s = [b ^ k for b, k in zip(s, round_keys[rnd])]
+    return bytes(s)
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """Starts the n ranks of this benchmark as child processes and relays rank 0's JSON line.  Runs before anything in
+    this process has touched the GPU (no torch.cuda call, no HIP call): the parent only waits."""
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if any(codes):
+        print(f"[bench] rank exit codes {codes}", file=sys.stderr)
+        raise SystemExit(1)
 
 
 def main():
@@ -139,45 +278,49 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aes", action="store_true")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            return launch_ranks(args.gpus, sys.argv[1:])
+        world, rank = 1, 0
+    else:
+        world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ.get("RANK", "0"))
+        if world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
 
     import torch
     import torch.distributed as dist
     from tfhe_aes_amd import engine as E
-    from tfhe_aes_amd import shard
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
-    if not torch.cuda.is_available():
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = "none"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")  # "gloo" rehearses several ranks on one GPU
+        os.environ.setdefault("MASTER_PORT", "29511")
+        backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")  # "gloo": the explicit switch to rehearse several ranks on one GPU
+        if backend == "nccl" and local_rank >= n_dev:
+            raise SystemExit(f"bench.py: rank {rank} has no GPU of its own ({n_dev} visible); RCCL needs one GPU per rank "
+                             "(set BENCH_DIST_BACKEND=gloo to rehearse on fewer GPUs)")
+    local_rank %= n_dev
+    torch.cuda.set_device(local_rank)
+    if world > 1:
         if backend == "nccl":
-            # one group with both transports: CUDA tensors travel over RCCL / xGMI, CPU tensors over gloo.  One probe
-            # collective, so that a broken fabric shows here and not after the timed steps; the timed path has no
-            # collective, so the gather and the barriers can fall back to gloo.
+            # CUDA tensors travel over RCCL / xGMI; CPU tensors (barriers, scalars) over gloo.  One probe collective so a
+            # broken fabric ends the run here, with a non-zero exit, and not behind a green line.
             dist.init_process_group("cpu:gloo,cuda:nccl", rank=rank, world_size=world)
-            try:
-                probe = torch.ones(1, device=torch.device("cuda", local_rank))
-                dist.all_reduce(probe)
-                torch.cuda.synchronize()
-                assert int(probe.item()) == world
-            except Exception as exc:
-                print(f"[bench] rank {rank}: RCCL unavailable ({exc!r}); collectives fall back to gloo", file=sys.stderr, flush=True)
-                backend = "gloo"
-            # every rank takes the same transport: one failed probe moves all of them to gloo
-            ok = torch.tensor([1 if backend == "nccl" else 0], dtype=torch.int32)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0:
-                backend = "gloo"
+            probe = torch.ones(1, device=torch.device("cuda", local_rank))
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+            if int(probe.item()) != world:
+                raise SystemExit(f"bench.py: RCCL probe all_reduce returned {probe.item()} on rank {rank}, expected {world}")
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    else:
-        backend = "none"
+    on_device = backend in ("nccl", "none")
 
-    coll_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     p = E.default_params()
     lwe_sk, glwe_sk, bsk, ksk = E.client_keygen(p, SEED)       # keys replicated: same seed on every rank
     ctx = E.Context(p, local_rank)
@@ -189,12 +332,9 @@ def main():
     even = np.arange(G) % 2 == 0
     gates = E.make_gates(np.where(even, E.NAND, E.XOR), np.arange(G), np.arange(G, 2 * G), None, np.arange(2 * G, 3 * G))
 
-    def dist_barrier():  # a collective on the transport in use (dist.barrier() would pick the CUDA one by itself)
-        dist.all_reduce(torch.zeros(1, device=coll_dev))
-
     def barrier():
         if world > 1:
-            dist_barrier()
+            dist.barrier()
         torch.cuda.synchronize()
         ctx.sync()
 
@@ -213,25 +353,38 @@ def main():
     st = ctx.stats()
     ctx.set_profiling(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # correctness of the timed work + the one collective of the path: gather a slice of the outputs
+    # correctness of the timed work + the one collective of the path: gather a slice of the outputs, device to device
     out = ctx.pool_read(np.arange(2 * G, 3 * G))
     got = E.client_decrypt(p, lwe_sk, out)
     wrong = int((got != np.where(even, 1 - (bits[:G] & bits[G:]), bits[:G] ^ bits[G:])).sum())
     gathered = None
     if world > 1:
-        gathered = shard.gather_blocks(out[None, :128], world, device=coll_dev)
-        w = torch.tensor([wrong], dtype=torch.int64, device=coll_dev)
+        from tfhe_aes_amd import shard
+        if on_device:
+            local = torch.empty((1, 128, p.lwe_dimension + 1), dtype=torch.int32, device=torch.device("cuda", local_rank))
+            ctx.pool_read_device(np.arange(2 * G, 2 * G + 128), local.data_ptr())
+            allb = shard.gather_blocks_device(local, world)
+            torch.cuda.synchronize()
+            mine_ok = bool((allb[rank].cpu().numpy().view(np.uint32) == out[:128]).all())
+            gathered = tuple(allb.shape)
+        else:
+            allb = shard.gather_blocks(out[None, :128], world)
+            mine_ok = bool((allb[rank] == out[:128]).all())
+            gathered = allb.shape
+        w = torch.tensor([wrong + (0 if mine_ok else 1)], dtype=torch.int64)
         dist.all_reduce(w)
         wrong = int(w.item())
 
+    line = None
     if rank == 0:
         pbs_ms = st.pbs_kernel_ms / max(1, st.pbs_launches)
         ks_ms = st.ks_kernel_ms / max(1, st.ks_launches)
         achieved = G * FLOP_PER_PBS / (pbs_ms * 1e-3) / 1e12 if pbs_ms > 0 else 0.0
+        traffic, traffic_src = measured_traffic()
         line = {
             "metric": METRIC, "value": round(world * G * args.steps / elapsed, 1), "unit": "gate bootstraps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -239,33 +392,37 @@ def main():
             "config": {"workload": "65536 independent tfhe::boolean NAND/XOR gate bootstraps per GPU (BASELINE configs[1])",
                        "gates_per_step_per_gpu": G, "params": "n=805,k=3,N=512,pbs=2^10x2,ks=2^3x5", "parallelism": f"replicas x{world}, keys replicated"},
             "wrong_results": wrong,
-            "roofline": {"bound": "mfma", "kernel": "pbs_kernel", "achieved": round(achieved, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP64_PEAK_TFLOPS, 4), "traffic": measured_traffic(), "traffic_unit": "HBM bytes per launch (rocprofv3 PMC passes, profiles/r1_pmc_summary.json)",
-                         "kernel_ms": round(pbs_ms, 3),
-                         "keyswitch_kernel_ms": round(ks_ms, 3)},
+            # the contract's two bounds are hbm and mfma; this kernel is bound by the fp64 arithmetic peak, which on
+            # MI355X is the same number for the vector units it runs on and for the matrix cores ("bound_detail")
+            "roofline": {"bound": "mfma", "bound_detail": "fp64 vector FMA units (peak equal to the fp64 matrix peak)", "kernel": "pbs_kernel",
+                         "achieved": round(achieved, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / FP64_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": f"HBM bytes per launch (rocprofv3 PMC passes, profiles/{traffic_src})",
+                         "kernel_ms": round(pbs_ms, 3), "keyswitch_kernel_ms": round(ks_ms, 3)},
         }
         if gathered is not None:
-            line["gathered_ciphertexts"] = int(gathered.shape[0] * gathered.shape[1])
+            line["gathered_ciphertexts"] = int(gathered[0] * gathered[1])
             line["collective_backend"] = "rccl" if backend == "nccl" else backend
+            line["gather"] = "device (all_gather_into_tensor on pool rows exported on the GPU)" if on_device else "host tensors"
     ctx.close()
     if not args.no_aes:
         # every rank takes part: 8 CTR blocks per GPU, max time over ranks
-        dt, n_blocks, ok = aes_ctr_sharded(local_rank, rank, world, coll_dev)
+        dt, n_blocks, ok = aes_ctr_sharded(local_rank, rank, world, on_device)
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+            t = torch.tensor([dt], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         if rank == 0:
             line["aes"] = {"ctr_blocks": n_blocks, "ctr_seconds": round(dt, 3), "ctr_s_per_block": round(dt / n_blocks, 4),
-                           "ctr_first_blocks_match_sp800_38a": ok, "sharding": f"block b on GPU b mod {world}, keys replicated, outputs gathered"}
+                           "ctr_all_blocks_correct": ok, "sharding": f"block b on GPU b mod {world}, keys replicated, outputs gathered"}
     if rank == 0:
         if world == 1 and not args.no_aes:
-            line["aes"].update(aes_block(local_rank))
+            line["aes"].update(aes_single_gpu(local_rank))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(p, lwe_sk, bsk, ksk)
         print(json.dumps(line), flush=True)
     if world > 1:
-        dist_barrier()
+        dist.barrier()
         dist.destroy_process_group()
 
 

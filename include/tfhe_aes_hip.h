@@ -70,6 +70,11 @@ int tfa_keys_upload(tfa_ctx *ctx, const uint32_t *bsk, const uint32_t *ksk);
 int tfa_pool_reserve(tfa_ctx *ctx, uint32_t n_slots);
 int tfa_pool_write(tfa_ctx *ctx, const uint32_t *slots, uint32_t count, const uint32_t *lwe /*[count][n+1]*/);
 int tfa_pool_read(tfa_ctx *ctx, const uint32_t *slots, uint32_t count, uint32_t *lwe /*[count][n+1]*/);
+/* The same read into DEVICE memory of the context's GPU: `d_out` receives [count][n+1] dense rows, complete on return, and
+ * can be handed to a collective as it is (the gather of output ciphertexts across GPUs; the reference's CTR mode leaves
+ * that step to the caller, /root/reference/modes/src/ctr.rs:8-10).  negate[i] != 0 writes the LWE negation of slot i
+ * (ServerKey::not on the way out); negate may be NULL. */
+int tfa_pool_read_device(tfa_ctx *ctx, const uint32_t *slots, const uint8_t *negate, uint32_t count, void *d_out);
 /* Device address/stride (in u32 words) of the pool, for zero-copy collectives. */
 int tfa_pool_device_ptr(tfa_ctx *ctx, void **dptr, uint32_t *stride_words, uint32_t *n_slots);
 
@@ -78,8 +83,8 @@ int tfa_pool_device_ptr(tfa_ctx *ctx, void **dptr, uint32_t *stride_words, uint3
  * per-bit loops of FHEByte::{xor,and,or}_in_place / mul_x_gf2_in_place (primitive.rs:96-133,
  * 349-362).  Asynchronous and ordered on the context's stream.  Every gate reads the pool as it was
  * before the stage: a bootstrapped gate may write a slot that it or any other gate of the stage reads
- * (the *_assign forms); a NOT/COPY may write its own input slot, but not one that another NOT/COPY of
- * the same stage reads, and two gates of a stage must not write the same slot. */
+ * (the *_assign forms); a NOT/COPY may write its own input slot.  Rejected with TFA_EINVAL, nothing launched: two
+ * gates of a stage writing the same slot, and a NOT/COPY writing a slot that another NOT/COPY of the stage reads. */
 int tfa_stage_submit(tfa_ctx *ctx, const tfa_gate *gates, uint32_t count);
 int tfa_sync(tfa_ctx *ctx);
 
@@ -97,7 +102,8 @@ const char *tfa_last_error(tfa_ctx *ctx);
 
 /* Client side (ClientKey::{encrypt,decrypt} and the key-material half of gen_keys();
  * /root/reference/base/src/primitive.rs:63,71,85, main.rs:64).  Host CPU, as in the reference.
- * seed == 0 draws the seed from the OS. */
+ * seed == 0 (production) keys the generator with 256 bits of OS entropy and returns TFA_ESTATE if the OS has none;
+ * a non-zero seed gives reproducible, NON-SECRET streams (64 bits of entropy) for tests and benchmarks. */
 int tfa_client_keygen(const tfa_params *p, uint64_t seed, uint32_t *lwe_sk /*[n]*/, uint32_t *glwe_sk /*[kN]*/,
                       uint32_t *bsk, uint32_t *ksk);
 int tfa_client_encrypt(const tfa_params *p, const uint32_t *lwe_sk, uint64_t seed, const uint8_t *bits, uint32_t count,

@@ -72,6 +72,9 @@ int tfh_state_xor_state(tfh_keys *k, tfh_state *s, const tfh_state *other);
 int tfh_state_decrypt_to_u8(tfh_keys *k, const tfh_state *s, uint8_t out[16]);
 /* the 128 LWE ciphertexts of a state ([16 bytes][8 bits, MSB first][n+1] words), for gathers */
 int tfh_state_read(tfh_keys *k, const tfh_state *s, uint32_t *out);
+/* the same for n states into device memory of the ServerKey's GPU ([n][128][n+1] words, dense): no host round trip
+ * before a collective */
+int tfh_states_read_device(tfh_keys *k, const tfh_state *const *states, uint32_t n, void *d_out);
 int tfh_state_import(tfh_keys *k, const uint32_t *lwe, tfh_state **out);
 void tfh_state_free(tfh_state *s);
 

@@ -75,6 +75,7 @@ extern "C" {
     pub fn tfa_pool_reserve(ctx: *mut tfa_ctx, n_slots: u32) -> c_int;
     pub fn tfa_pool_write(ctx: *mut tfa_ctx, slots: *const u32, count: u32, lwe: *const u32) -> c_int;
     pub fn tfa_pool_read(ctx: *mut tfa_ctx, slots: *const u32, count: u32, lwe: *mut u32) -> c_int;
+    pub fn tfa_pool_read_device(ctx: *mut tfa_ctx, slots: *const u32, negate: *const u8, count: u32, d_out: *mut c_void) -> c_int;
     pub fn tfa_pool_device_ptr(ctx: *mut tfa_ctx, dptr: *mut *mut c_void, stride_words: *mut u32, n_slots: *mut u32) -> c_int;
     pub fn tfa_stage_submit(ctx: *mut tfa_ctx, gates: *const tfa_gate, count: u32) -> c_int;
     pub fn tfa_sync(ctx: *mut tfa_ctx) -> c_int;

@@ -97,8 +97,9 @@ def test_blind_rotation_prefix_bit_exact(gpu_ctx, oracle, okeys):
         got = gpu_ctx.blind_rotate_batch(cts, steps)
         for g in range(3):
             ref = oracle.blind_rotate(okeys[2], None, cts[g], steps)
-            assert np.abs(sdiff(got[g], ref)).max() <= 1, (steps, g)
-            assert (got[g] == ref).mean() > 0.999
+            # every word equal; on failure the message carries the size of the disagreement (the FFT noise bound is
+            # the fallback diagnostic, not the bar)
+            assert (got[g] == ref).all(), (steps, g, int(np.abs(sdiff(got[g], ref)).max()), float((got[g] == ref).mean()))
 
 
 def test_bootstrap_against_exact_oracle(gpu_ctx, oracle, okeys):
@@ -223,16 +224,16 @@ def test_mixed_gates_with_negations(gpu_ctx, oracle, okeys, obsk_f):
     out = gpu_ctx.pool_read(np.arange(3 * G, 4 * G))
     exp = clear_gate(ops, a ^ (neg & 1), b ^ ((neg >> 1) & 1), c ^ ((neg >> 2) & 1))
     assert (oracle.decrypt_bits(lwe_sk, out) == exp).all()
-    # word-for-word against the oracle on a sample (negation = LWE negation of the operand)
-    idx = np.arange(0, G, G // 24)[:24]
+    # word-for-word against the EXACT-integer oracle on a sample (negation = LWE negation of the operand): every
+    # sampled row identical.  (The oracle's own fp64-FFT engine is a different rounding sequence and may differ from
+    # the exact engine in a digit now and then; the GPU is held to the exact one.)
+    idx = np.arange(0, G, G // 16)[:16]
     flip = lambda ct, m: np.where(m[:, None] == 1, (0 - ct.astype(np.int64)) % 2**32, ct).astype(np.uint32)
-    ref = oracle.gates(bsk, obsk_f, ksk, ops[idx].astype(np.uint8), flip(ca[idx], neg[idx] & 1), flip(cb[idx], (neg[idx] >> 1) & 1),
+    ref = oracle.gates(bsk, None, ksk, ops[idx].astype(np.uint8), flip(ca[idx], neg[idx] & 1), flip(cb[idx], (neg[idx] >> 1) & 1),
                        flip(cc[idx], (neg[idx] >> 2) & 1))
     same = (ref == out[idx]).all(axis=1)
-    assert same.sum() >= 22
-    for i in np.nonzero(~same)[0]:
-        d = (oracle.phase(lwe_sk, ref[i]) - oracle.phase(lwe_sk, out[idx[i]]) + 2**31) % 2**32 - 2**31
-        assert abs(d) <= 64 * FFT_NOISE_BOUND
+    diag = [int((oracle.phase(lwe_sk, ref[i]) - oracle.phase(lwe_sk, out[idx[i]]) + 2**31) % 2**32 - 2**31) for i in np.nonzero(~same)[0]]
+    assert same.all(), f"rows differing from the exact oracle: {np.nonzero(~same)[0].tolist()}, phase differences {diag} (FFT noise bound {FFT_NOISE_BOUND})"
 
 
 def test_not_copy_and_chained_stages(gpu_ctx, oracle, okeys):
@@ -269,6 +270,61 @@ def test_in_place_gates_read_the_pool_as_it_was_before_the_stage(gpu_ctx, oracle
     got = oracle.decrypt_bits(lwe_sk, gpu_ctx.pool_read([0, 1, 2, 3, 5, 10]))
     b = bits
     assert list(got) == [b[0] ^ b[1], b[0] & b[1], b[2] | b[0], (b[0] if b[3] else b[4]), 1 - b[5], b[1]]
+
+
+def test_stage_hazards_are_rejected(gpu_ctx, oracle, okeys):
+    """Two gates writing one slot, and a NOT/COPY writing a slot that another NOT/COPY of the stage reads, are refused
+    before anything is launched (the pool keeps its contents); the legal neighbours of those cases still run."""
+    lwe_sk = okeys[0]
+    bits = np.array([1, 0, 1, 0], np.uint8)
+    gpu_ctx.pool_reserve(32)
+    gpu_ctx.pool_write(np.arange(4), oracle.encrypt_bits(lwe_sk, 84, 0, bits))
+    before = gpu_ctx.pool_read(np.arange(12))
+    with pytest.raises(E.TfaError, match="two gates of one stage write slot 8"):
+        gpu_ctx.stage_submit(E.make_gates([E.AND, E.XOR], [0, 1], [1, 2], None, [8, 8]))
+    with pytest.raises(E.TfaError, match="two gates of one stage write slot 9"):
+        gpu_ctx.stage_submit(E.make_gates([E.MUX, E.COPY], [0, 1], [1, 0], [2, 0], [9, 9]))
+    with pytest.raises(E.TfaError, match="another NOT/COPY of the stage reads"):
+        gpu_ctx.stage_submit(E.make_gates([E.NOT, E.COPY], [0, 8], [0, 0], None, [8, 9]))      # chained: COPY reads what NOT writes
+    with pytest.raises(E.TfaError, match="another NOT/COPY of the stage reads"):
+        gpu_ctx.stage_submit(E.make_gates([E.NOT, E.COPY], [0, 0], [0, 0], None, [0, 9]))      # in place under a second reader
+    with pytest.raises(E.TfaError, match="another NOT/COPY of the stage reads"):
+        gpu_ctx.stage_submit(E.make_gates([E.COPY, E.NOT], [1, 2], [0, 0], None, [2, 1]))  # a swap through NOT/COPY
+    gpu_ctx.sync()
+    assert (gpu_ctx.pool_read(np.arange(12)) == before).all()
+    # legal: NOT in place (sole reader), a bootstrapped gate reading a slot that a NOT of the same stage overwrites
+    gpu_ctx.stage_submit(E.make_gates([E.NOT, E.AND, E.COPY], [0, 0, 1], [0, 2, 0], None, [0, 8, 9]))
+    gpu_ctx.sync()
+    got = oracle.decrypt_bits(lwe_sk, gpu_ctx.pool_read([0, 8, 9]))
+    assert list(got) == [1 - bits[0], bits[0] & bits[2], bits[1]]
+
+
+def test_keyswitch_other_parameters_vector_path(oracle):
+    """The vector keyswitch is generic in (n, base, levels): n = 700 (not 805), 2^4 x 4 levels (not 2^3 x 5), where
+    the matrix-core kernel does not apply, at every tile width, against the oracle under the same parameters; and a
+    dimension beyond the kernel's 806 output columns is refused at context creation."""
+    from oracle.pyoracle import Oracle
+    o = Oracle()
+    o.params.lwe_dimension, o.params.ks_base_log, o.params.ks_level = 700, 4, 4
+    keys = o.keygen(0x1234)
+    p = E.default_params()
+    p.lwe_dimension, p.ks_base_log, p.ks_level = 700, 4, 4
+    ctx = E.Context(p, 0)
+    try:
+        ctx.keys_upload(keys[2], keys[3])
+        rng = np.random.default_rng(6)
+        for count in (1, 37, 300, 2500, 8200):
+            big = rng.integers(0, 2**32, (count, ctx.big + 1), dtype=np.uint64).astype(np.uint32)
+            big[0, :4] = (0, 0xFFFFFFFF, 0x80000000, 0x00008000)   # the last: a rounding tie at 16 representable bits
+            got = ctx.keyswitch_batch(big)
+            assert got.shape == (count, 701)
+            for i in (0, count // 2, count - 1):
+                assert (got[i] == o.keyswitch(keys[3], big[i])).all(), (count, i)
+    finally:
+        ctx.close()
+    p.lwe_dimension = 806
+    with pytest.raises(E.TfaError):
+        E.Context(p, 0)
 
 
 def test_two_contexts_with_different_keys_run_interleaved(gpu_ctx, oracle, okeys):

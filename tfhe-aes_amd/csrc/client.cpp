@@ -3,8 +3,12 @@
 // tfhe::boolean::gen_keys() and ClientKey::{encrypt,decrypt} run on the client
 // (/root/reference/tfhe-aes/src/main.rs:64, /root/reference/base/src/primitive.rs:63,71,85).
 //
-// Randomness: ChaCha20 keyed from a 64-bit seed (seed 0 = draw one from the OS), one stream per
-// key component so generation parallelises deterministically.
+// Randomness: ChaCha20, one stream per key component so generation parallelises deterministically.  seed == 0 (the
+// production setting, what gen_keys() of the reference does) keys the cipher with 256 bits of OS entropy and fails
+// when the OS has none to give.  A non-zero 64-bit seed expands to the key through splitmix64: reproducible streams for
+// tests and benchmarks, NOT secret (64 bits of entropy at most).
+#include <sys/random.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -26,12 +30,14 @@ struct ChaCha {
         z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
         return z ^ (z >> 31);
     }
-    ChaCha(uint64_t seed, uint64_t stream_id) : stream(stream_id) {
+    ChaCha(const uint32_t (&k)[8], uint64_t stream_id) : stream(stream_id) { std::memcpy(key, k, sizeof key); }
+    // test / benchmark keys: the 64-bit seed stretched by splitmix64
+    static void key_from_seed(uint64_t seed, uint32_t (&k)[8]) {
         uint64_t s = seed;
         for (int i = 0; i < 4; i++) {
             uint64_t v = mix(s);
-            key[2 * i] = (uint32_t)v;
-            key[2 * i + 1] = (uint32_t)(v >> 32);
+            k[2 * i] = (uint32_t)v;
+            k[2 * i + 1] = (uint32_t)(v >> 32);
         }
     }
     static inline uint32_t rotl(uint32_t v, int c) { return (v << c) | (v >> (32 - c)); }
@@ -84,14 +90,26 @@ struct ChaCha {
     }
 };
 
-uint64_t os_seed() {
-    uint64_t s = 0;
-    FILE *f = std::fopen("/dev/urandom", "rb");
-    if (f) {
-        if (std::fread(&s, sizeof s, 1, f) != 1) s = 0;
-        std::fclose(f);
+// 256 bits from the OS (getrandom, else /dev/urandom); false when neither delivers
+bool os_key(uint32_t (&k)[8]) {
+    size_t got = 0;
+    unsigned char *dst = reinterpret_cast<unsigned char *>(k);
+    while (got < sizeof k) {
+        ssize_t r = getrandom(dst + got, sizeof k - got, 0);
+        if (r <= 0) break;
+        got += (size_t)r;
     }
-    return s ? s : 0x5446484541455321ull;
+    if (got == sizeof k) return true;
+    FILE *f = std::fopen("/dev/urandom", "rb");
+    if (!f) return false;
+    const bool ok = std::fread(k, sizeof k, 1, f) == 1;
+    std::fclose(f);
+    return ok;
+}
+bool make_key(uint64_t seed, uint32_t (&k)[8]) {
+    if (seed == 0) return os_key(k);
+    ChaCha::key_from_seed(seed, k);
+    return true;
 }
 
 // body += mask * key (negacyclic, binary key)
@@ -112,21 +130,22 @@ bool params_ok(const tfa_params *p) {
 
 extern "C" int tfa_client_keygen(const tfa_params *p, uint64_t seed, uint32_t *lwe_sk, uint32_t *glwe_sk, uint32_t *bsk, uint32_t *ksk) {
     if (!params_ok(p) || !lwe_sk || !glwe_sk || !bsk || !ksk) return TFA_EINVAL;
-    if (seed == 0) seed = os_seed();
+    uint32_t seed_key[8];
+    if (!make_key(seed, seed_key)) return TFA_ESTATE;  // no OS entropy: never fall back to a fixed key
     const uint32_t n = p->lwe_dimension, k = p->glwe_dimension, N = p->polynomial_size, l = p->pbs_level, k1 = k + 1;
     {
-        ChaCha r(seed, 1);
+        ChaCha r(seed_key, 1);
         for (uint32_t i = 0; i < n; i++) lwe_sk[i] = r.u32() & 1u;
     }
     {
-        ChaCha r(seed, 2);
+        ChaCha r(seed_key, 2);
         for (uint32_t i = 0; i < k * N; i++) glwe_sk[i] = r.u32() & 1u;
     }
     // bootstrapping key: GGSW(s_i), rows = GLWE encryptions of zero plus s_i * q / beta^j on polynomial `row`
     const uint64_t ggsw_words = (uint64_t)l * k1 * k1 * N;
 #pragma omp parallel for schedule(dynamic, 8)
     for (uint32_t i = 0; i < n; i++) {
-        ChaCha masks(seed, (3ull << 32) | i), noise(seed, (4ull << 32) | i);
+        ChaCha masks(seed_key, (3ull << 32) | i), noise(seed_key, (4ull << 32) | i);
         uint32_t *ggsw = bsk + (uint64_t)i * ggsw_words;
         for (uint32_t j = 0; j < l; j++)
             for (uint32_t row = 0; row < k1; row++) {
@@ -142,7 +161,7 @@ extern "C" int tfa_client_keygen(const tfa_params *p, uint64_t seed, uint32_t *l
     const uint32_t lk = p->ks_level, big = k * N;
 #pragma omp parallel for schedule(dynamic, 16)
     for (uint32_t i = 0; i < big; i++) {
-        ChaCha masks(seed, (5ull << 32) | i), noise(seed, (6ull << 32) | i);
+        ChaCha masks(seed_key, (5ull << 32) | i), noise(seed_key, (6ull << 32) | i);
         uint32_t e[64];
         noise.gauss_fill(p->lwe_noise_std, e, lk);
         for (uint32_t j = 0; j < lk; j++) {
@@ -161,9 +180,10 @@ extern "C" int tfa_client_keygen(const tfa_params *p, uint64_t seed, uint32_t *l
 
 extern "C" int tfa_client_encrypt(const tfa_params *p, const uint32_t *lwe_sk, uint64_t seed, const uint8_t *bits, uint32_t count, uint32_t *lwe) {
     if (!params_ok(p) || !lwe_sk || (!bits && count) || (!lwe && count)) return TFA_EINVAL;
-    if (seed == 0) seed = os_seed();
+    uint32_t seed_key[8];
+    if (!make_key(seed, seed_key)) return TFA_ESTATE;
     const uint32_t n = p->lwe_dimension;
-    ChaCha masks(seed, 7ull << 32), noise(seed, (7ull << 32) ^ 1ull);
+    ChaCha masks(seed_key, 7ull << 32), noise(seed_key, (7ull << 32) ^ 1ull);
     for (uint32_t g = 0; g < count; g++) {
         uint32_t *ct = lwe + (uint64_t)g * (n + 1), e0, e1;
         noise.gauss2(p->lwe_noise_std, e0, e1);

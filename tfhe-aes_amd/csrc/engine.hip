@@ -2,6 +2,7 @@
 // the per-stage batch submitter.  One context per GPU, one submitting thread per context.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -62,6 +63,11 @@ struct tfa_ctx {
     bool trace = false;   // TFA_TRACE=1: one stderr line per submitted stage
     int force_waves = 0;  // 0 = choose per launch; 1 / 2 (latency kernel, workgroups per CU), 4 or 8 pins the kernel variant (TFA_PBS_WAVES, for experiments)
     std::vector<EventPair> pending;
+    // per-stage validation marks, sized with the pool: slot_mark[s] = stamp of the stage that last wrote s,
+    // lin_reader[s] = (stamp << 32) | index + 1 of the NOT/COPY gate reading s (all ones: several)
+    std::vector<uint32_t> slot_mark;
+    std::vector<uint64_t> lin_reader;
+    uint32_t mark_stamp = 0;
 };
 
 #define HIPCHK(ctx, call)                                                                                      \
@@ -172,7 +178,8 @@ extern "C" int tfa_ctx_create(const tfa_params *p, int hip_device, tfa_ctx **out
     if (!p || !out) return TFA_EINVAL;
     *out = nullptr;
     if (p->glwe_dimension != 3 || p->polynomial_size != 512 || p->pbs_base_log != 10 || p->pbs_level != 2) return TFA_EINVAL;
-    if (p->lwe_dimension < 1 || p->lwe_dimension > 830 || p->ks_level < 1 || p->ks_level > kKsMaxLevels ||
+    // the vector keyswitch maps its n + 1 output columns onto 13 waves x 62 lanes = 806 columns of one workgroup
+    if (p->lwe_dimension < 1 || p->lwe_dimension + 1 > 13 * kKsLanesUsed || p->ks_level < 1 || p->ks_level > kKsMaxLevels ||
         p->ks_base_log * p->ks_level > 31 || p->ks_base_log < 1)
         return TFA_EINVAL;
     int n_dev = 0;
@@ -312,6 +319,8 @@ extern "C" int tfa_pool_reserve(tfa_ctx *ctx, uint32_t n_slots) {
     if (ctx->d_pool) hipFree(ctx->d_pool);
     ctx->d_pool = np_;
     ctx->pool_slots = n_slots;
+    ctx->slot_mark.resize(n_slots, 0u);
+    ctx->lin_reader.resize(n_slots, 0u);
     return TFA_OK;
 }
 
@@ -363,6 +372,33 @@ extern "C" int tfa_pool_read(tfa_ctx *ctx, const uint32_t *slots, uint32_t count
     return TFA_OK;
 }
 
+extern "C" int tfa_pool_read_device(tfa_ctx *ctx, const uint32_t *slots, const uint8_t *negate, uint32_t count, void *d_out) {
+    if (!ctx || !slots || !d_out) return TFA_EINVAL;
+    if (count == 0) return TFA_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = check_slots(ctx, slots, count);
+    if (rc) return rc;
+    if (ctx->pool_slots > 0x80000000u) return fail(ctx, TFA_EINVAL, "pool too large for tagged slot indices");
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, d_out) != hipSuccess || attr.type != hipMemoryTypeDevice || attr.device != ctx->device) {
+        (void)hipGetLastError();
+        return fail(ctx, TFA_EINVAL, "tfa_pool_read_device: destination is not device memory of the context's GPU");
+    }
+    const size_t slot_bytes = (size_t)count * sizeof(uint32_t);
+    rc = ensure_io(ctx, slot_bytes);
+    if (rc) return rc;
+    std::vector<uint32_t> tagged(slots, slots + count);
+    if (negate)
+        for (uint32_t i = 0; i < count; i++)
+            if (negate[i]) tagged[i] |= 0x80000000u;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_io, tagged.data(), slot_bytes, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(pool_export_kernel, dim3(count), dim3(256), 0, ctx->stream, ctx->d_pool, ctx->pool_stride, ctx->d_io,
+                       static_cast<uint32_t *>(d_out), ctx->p.lwe_dimension + 1);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the rows are complete (and `tagged` may go) on return
+    return TFA_OK;
+}
+
 extern "C" int tfa_pool_device_ptr(tfa_ctx *ctx, void **dptr, uint32_t *stride_words, uint32_t *n_slots) {
     if (!ctx) return TFA_EINVAL;
     if (dptr) *dptr = ctx->d_pool;
@@ -373,10 +409,11 @@ extern "C" int tfa_pool_device_ptr(tfa_ctx *ctx, void **dptr, uint32_t *stride_w
 
 // ---------------------------------------------------------------------------------------------
 static int launch_pbs(tfa_ctx *ctx, const uint32_t *in_base, uint32_t in_stride, const PbsJob *d_jobs, uint32_t n_jobs, uint32_t steps,
-                      uint32_t *acc_out) {
+                      uint32_t *acc_out, uint32_t *big_base, bool timed = true) {
     if (n_jobs == 0) return TFA_OK;
     EventPair ep{nullptr, nullptr, 0};
-    if (ctx->profiling) {
+    const bool profiling = ctx->profiling && timed;
+    if (profiling) {
         HIPCHK(ctx, hipEventCreate(&ep.a));
         HIPCHK(ctx, hipEventCreate(&ep.b));
         HIPCHK(ctx, hipEventRecord(ep.a, ctx->stream));
@@ -397,7 +434,7 @@ static int launch_pbs(tfa_ctx *ctx, const uint32_t *in_base, uint32_t in_stride,
     };
     auto launch = [&](int variant, uint32_t first, uint32_t count) {
         const PbsJob *jobs = d_jobs + first;
-        uint32_t *big = ctx->d_big + (size_t)first * ctx->big_stride;
+        uint32_t *big = big_base + (size_t)first * ctx->big_stride;
         uint32_t *acc = acc_out ? acc_out + (size_t)first * kK1 * kN : nullptr;
         if (variant == 8)
             hipLaunchKernelGGL(pbs_kernel<8>, dim3((count + 7) / 8), dim3(512), PbsGeom<8>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
@@ -425,7 +462,7 @@ static int launch_pbs(tfa_ctx *ctx, const uint32_t *in_base, uint32_t in_stride,
         launch(variant, 0, n_jobs);
     }
     HIPCHK(ctx, hipGetLastError());
-    if (ctx->profiling) {
+    if (profiling) {
         HIPCHK(ctx, hipEventRecord(ep.b, ctx->stream));
         ctx->pending.push_back(ep);
     }
@@ -433,11 +470,13 @@ static int launch_pbs(tfa_ctx *ctx, const uint32_t *in_base, uint32_t in_stride,
     return TFA_OK;
 }
 
-static int launch_ks(tfa_ctx *ctx, const KsJob *d_jobs, uint32_t n_jobs, uint32_t *out_base, uint32_t out_stride) {
+static int launch_ks(tfa_ctx *ctx, const KsJob *d_jobs, uint32_t n_jobs, uint32_t *out_base, uint32_t out_stride, const uint32_t *big_base,
+                     bool timed = true) {
     if (n_jobs == 0) return TFA_OK;
     const tfa_params &p = ctx->p;
     EventPair ep{nullptr, nullptr, 1};
-    if (ctx->profiling) {
+    const bool profiling = ctx->profiling && timed;
+    if (profiling) {
         HIPCHK(ctx, hipEventCreate(&ep.a));
         HIPCHK(ctx, hipEventCreate(&ep.b));
         HIPCHK(ctx, hipEventRecord(ep.a, ctx->stream));
@@ -447,10 +486,10 @@ static int launch_ks(tfa_ctx *ctx, const KsJob *d_jobs, uint32_t n_jobs, uint32_
     // narrower stages are latency-bound and stay on the vector kernels, which split the key stream over all CUs.
     if (ctx->d_ksk8 && !ctx->ks_valu && n_jobs >= 256) {
         hipLaunchKernelGGL(keyswitch_mfma_kernel<5>, dim3((n_jobs + kKsmGates - 1) / kKsmGates, (p.lwe_dimension + 1 + kKsmCols - 1) / kKsmCols), dim3(256), 0,
-                           ctx->stream, ctx->d_big, ctx->big_stride, d_jobs, n_jobs, ctx->d_ksk8, p.lwe_dimension, big_dim, p.ks_base_log, out_base,
+                           ctx->stream, big_base, ctx->big_stride, d_jobs, n_jobs, ctx->d_ksk8, p.lwe_dimension, big_dim, p.ks_base_log, out_base,
                            out_stride);
         HIPCHK(ctx, hipGetLastError());
-        if (ctx->profiling) {
+        if (profiling) {
             HIPCHK(ctx, hipEventRecord(ep.b, ctx->stream));
             ctx->pending.push_back(ep);
         }
@@ -459,7 +498,7 @@ static int launch_ks(tfa_ctx *ctx, const KsJob *d_jobs, uint32_t n_jobs, uint32_
     }
 #define KS_LAUNCH(TG, UNROLL, SPLIT)                                                                                                         \
     hipLaunchKernelGGL((keyswitch_kernel<TG, UNROLL>), dim3((n_jobs + TG - 1) / TG, SPLIT), dim3(832), kKsChunk *p.ks_level *TG * sizeof(int32_t), \
-                       ctx->stream, ctx->d_big, ctx->big_stride, d_jobs, n_jobs, ctx->d_ksk, ctx->ksk_stride, p.lwe_dimension, big_dim,            \
+                       ctx->stream, big_base, ctx->big_stride, d_jobs, n_jobs, ctx->d_ksk, ctx->ksk_stride, p.lwe_dimension, big_dim,            \
                        p.ks_base_log, p.ks_level, out_base, out_stride)
     if (n_jobs >= 32 * 256) {
         KS_LAUNCH(32, 2, 1);
@@ -471,7 +510,7 @@ static int launch_ks(tfa_ctx *ctx, const KsJob *d_jobs, uint32_t n_jobs, uint32_
         uint32_t split = (ctx->n_cus + tiles - 1) / tiles;
         if (split > chunks) split = chunks;
         if (split > 1) {
-            hipLaunchKernelGGL(keyswitch_init_kernel, dim3(n_jobs), dim3(256), 0, ctx->stream, ctx->d_big, ctx->big_stride, d_jobs, n_jobs,
+            hipLaunchKernelGGL(keyswitch_init_kernel, dim3(n_jobs), dim3(256), 0, ctx->stream, big_base, ctx->big_stride, d_jobs, n_jobs,
                                p.lwe_dimension, big_dim, out_base, out_stride);
             HIPCHK(ctx, hipGetLastError());
         }
@@ -479,7 +518,7 @@ static int launch_ks(tfa_ctx *ctx, const KsJob *d_jobs, uint32_t n_jobs, uint32_
     }
 #undef KS_LAUNCH
     HIPCHK(ctx, hipGetLastError());
-    if (ctx->profiling) {
+    if (profiling) {
         HIPCHK(ctx, hipEventRecord(ep.b, ctx->stream));
         ctx->pending.push_back(ep);
     }
@@ -487,37 +526,66 @@ static int launch_ks(tfa_ctx *ctx, const KsJob *d_jobs, uint32_t n_jobs, uint32_
     return TFA_OK;
 }
 
-extern "C" int tfa_stage_submit(tfa_ctx *ctx, const tfa_gate *gates, uint32_t count) {
-    if (!ctx || (!gates && count)) return TFA_EINVAL;
-    if (count == 0) return TFA_OK;
-    if (!ctx->have_keys) return fail(ctx, TFA_ESTATE, "tfa_stage_submit before tfa_keys_upload");
-    if (!ctx->d_pool) return fail(ctx, TFA_ESTATE, "tfa_stage_submit before tfa_pool_reserve");
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    // translate gates into bootstrap, keyswitch and linear jobs
+// Gates of a stage -> bootstrap, keyswitch and linear jobs, written into `h` (sized by stage_layout).
+struct StageLayout {
     uint32_t n_pbs = 0, n_ks = 0, n_lin = 0;
+    size_t off_ks = 0, off_lin = 0, total = 0;
+};
+
+// Checks one stage and counts its jobs.  Rejected: unknown opcodes, slots outside the pool, two gates writing one slot,
+// and a NOT/COPY writing a slot that another NOT/COPY of the stage reads (the linear jobs run concurrently; every
+// bootstrapped gate reads the pool as it was before the stage, so those may overlap freely).
+static int stage_layout(tfa_ctx *ctx, const tfa_gate *gates, uint32_t count, StageLayout *out) {
+    StageLayout L;
+    if (ctx->slot_mark.size() < ctx->pool_slots) return fail(ctx, TFA_ESTATE, "slot marks not sized (tfa_pool_reserve)");
+    if (ctx->mark_stamp >= 0x7FFFFFF0u) {  // stamps are about to wrap: clear once
+        std::fill(ctx->slot_mark.begin(), ctx->slot_mark.end(), 0u);
+        std::fill(ctx->lin_reader.begin(), ctx->lin_reader.end(), 0u);
+        ctx->mark_stamp = 0;
+    }
+    const uint32_t stamp = ++ctx->mark_stamp;
+    bool any_lin = false;
     for (uint32_t i = 0; i < count; i++) {
         const tfa_gate &g = gates[i];
         if (g.op > TFA_COPY) return fail(ctx, TFA_EINVAL, "unknown gate opcode");
         if (g.in0 >= ctx->pool_slots || g.out >= ctx->pool_slots) return fail(ctx, TFA_EINVAL, "gate slot out of range");
         if (g.op <= TFA_MUX && g.in1 >= ctx->pool_slots) return fail(ctx, TFA_EINVAL, "gate slot out of range");
         if (g.op == TFA_MUX && g.in2 >= ctx->pool_slots) return fail(ctx, TFA_EINVAL, "gate slot out of range");
+        if (ctx->slot_mark[g.out] == stamp) return fail(ctx, TFA_EINVAL, "two gates of one stage write slot " + std::to_string(g.out));
+        ctx->slot_mark[g.out] = stamp;
         if (g.op == TFA_MUX) {
-            n_pbs += 2;
-            n_ks++;
+            L.n_pbs += 2;
+            L.n_ks++;
         } else if (g.op <= TFA_XNOR) {
-            n_pbs++;
-            n_ks++;
-        } else
-            n_lin++;
+            L.n_pbs++;
+            L.n_ks++;
+        } else {
+            L.n_lin++;
+            any_lin = true;
+            // remember who reads in0 among the linear gates: gate index + 1 under the stamp, or "several"
+            uint64_t &r = ctx->lin_reader[g.in0];
+            r = ((uint32_t)(r >> 32) == stamp) ? (((uint64_t)stamp << 32) | 0xFFFFFFFFu) : (((uint64_t)stamp << 32) | (i + 1));
+        }
     }
-    const size_t off_ks = (sizeof(PbsJob) * n_pbs + 15) / 16 * 16, off_lin = off_ks + (sizeof(KsJob) * n_ks + 15) / 16 * 16;
-    const size_t total = off_lin + sizeof(LinJob) * n_lin;
-    unsigned char *h = nullptr;
-    int slot = staging(ctx, total, &h);
-    if (slot < 0) return slot;
+    if (any_lin)
+        for (uint32_t i = 0; i < count; i++) {
+            const tfa_gate &g = gates[i];
+            if (g.op < TFA_NOT) continue;
+            const uint64_t r = ctx->lin_reader[g.out];
+            if ((uint32_t)(r >> 32) == stamp && (uint32_t)r != i + 1)
+                return fail(ctx, TFA_EINVAL, "a NOT/COPY writes slot " + std::to_string(g.out) + ", which another NOT/COPY of the stage reads");
+        }
+    L.off_ks = (sizeof(PbsJob) * L.n_pbs + 15) / 16 * 16;
+    L.off_lin = L.off_ks + (sizeof(KsJob) * L.n_ks + 15) / 16 * 16;
+    L.total = L.off_lin + sizeof(LinJob) * L.n_lin;
+    *out = L;
+    return TFA_OK;
+}
+
+static void stage_translate(const tfa_gate *gates, uint32_t count, const StageLayout &L, unsigned char *h) {
     PbsJob *pj = reinterpret_cast<PbsJob *>(h);
-    KsJob *kj = reinterpret_cast<KsJob *>(h + off_ks);
-    LinJob *lj = reinterpret_cast<LinJob *>(h + off_lin);
+    KsJob *kj = reinterpret_cast<KsJob *>(h + L.off_ks);
+    LinJob *lj = reinterpret_cast<LinJob *>(h + L.off_lin);
     const uint32_t T = 1u << 29;
     uint32_t ip = 0, ik = 0, il = 0;
     for (uint32_t i = 0; i < count; i++) {
@@ -544,23 +612,43 @@ extern "C" int tfa_stage_submit(tfa_ctx *ctx, const tfa_gate *gates, uint32_t co
         kj[ik++] = KsJob{ip, kNoSlot, 0u, g.out};
         ip++;
     }
-    int rc = ensure_jobs(ctx, total);
-    if (rc) return rc;
-    if (ctx->trace) fprintf(stderr, "tfa stage: gates=%u pbs=%u ks=%u lin=%u\n", count, n_pbs, n_ks, n_lin);
-    rc = ensure_big(ctx, n_pbs);
-    if (rc) return rc;
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_jobs, h, total, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipEventRecord(ctx->h_stage_ev[slot], ctx->stream));
-    rc = launch_pbs(ctx, ctx->d_pool, ctx->pool_stride, reinterpret_cast<const PbsJob *>(ctx->d_jobs), n_pbs, ctx->p.lwe_dimension, nullptr);
+}
+
+// The three launches of a stage on job lists at `d_jobs` and big-LWE rows at `d_big`.
+static int stage_launch(tfa_ctx *ctx, const StageLayout &L, unsigned char *d_jobs, uint32_t *d_big, bool timed) {
+    int rc = launch_pbs(ctx, ctx->d_pool, ctx->pool_stride, reinterpret_cast<const PbsJob *>(d_jobs), L.n_pbs, ctx->p.lwe_dimension, nullptr, d_big, timed);
     if (rc) return rc;
     // NOT/COPY before the keyswitch, the only writer of bootstrapped results: every gate of the stage, linear ones
     // included, reads the pool as it was before the stage, so a gate may write the slot it (or another gate) reads.
-    if (n_lin) {
-        hipLaunchKernelGGL(lin_kernel, dim3(n_lin), dim3(256), 0, ctx->stream, ctx->d_pool, ctx->pool_stride,
-                           reinterpret_cast<const LinJob *>(ctx->d_jobs + off_lin), n_lin, ctx->p.lwe_dimension);
+    if (L.n_lin) {
+        hipLaunchKernelGGL(lin_kernel, dim3(L.n_lin), dim3(256), 0, ctx->stream, ctx->d_pool, ctx->pool_stride,
+                           reinterpret_cast<const LinJob *>(d_jobs + L.off_lin), L.n_lin, ctx->p.lwe_dimension);
         HIPCHK(ctx, hipGetLastError());
     }
-    rc = launch_ks(ctx, reinterpret_cast<const KsJob *>(ctx->d_jobs + off_ks), n_ks, ctx->d_pool, ctx->pool_stride);
+    return launch_ks(ctx, reinterpret_cast<const KsJob *>(d_jobs + L.off_ks), L.n_ks, ctx->d_pool, ctx->pool_stride, d_big, timed);
+}
+
+extern "C" int tfa_stage_submit(tfa_ctx *ctx, const tfa_gate *gates, uint32_t count) {
+    if (!ctx || (!gates && count)) return TFA_EINVAL;
+    if (count == 0) return TFA_OK;
+    if (!ctx->have_keys) return fail(ctx, TFA_ESTATE, "tfa_stage_submit before tfa_keys_upload");
+    if (!ctx->d_pool) return fail(ctx, TFA_ESTATE, "tfa_stage_submit before tfa_pool_reserve");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    StageLayout L;
+    int rc = stage_layout(ctx, gates, count, &L);
+    if (rc) return rc;
+    unsigned char *h = nullptr;
+    int slot = staging(ctx, L.total, &h);
+    if (slot < 0) return slot;
+    stage_translate(gates, count, L, h);
+    rc = ensure_jobs(ctx, L.total);
+    if (rc) return rc;
+    if (ctx->trace) fprintf(stderr, "tfa stage: gates=%u pbs=%u ks=%u lin=%u\n", count, L.n_pbs, L.n_ks, L.n_lin);
+    rc = ensure_big(ctx, L.n_pbs);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_jobs, h, L.total, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->h_stage_ev[slot], ctx->stream));
+    rc = stage_launch(ctx, L, ctx->d_jobs, ctx->d_big, true);
     if (rc) return rc;
     ctx->stats.gate_count += count;
     ctx->stats.stage_count++;
@@ -597,7 +685,7 @@ static int bootstrap_common(tfa_ctx *ctx, const uint32_t *lwe_in, uint32_t count
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_jobs, jobs.data(), sizeof(PbsJob) * count, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     rc = launch_pbs(ctx, reinterpret_cast<const uint32_t *>(io), words, reinterpret_cast<const PbsJob *>(ctx->d_jobs), count, steps,
-                    acc_host ? reinterpret_cast<uint32_t *>(io + acc_off) : nullptr);
+                    acc_host ? reinterpret_cast<uint32_t *>(io + acc_off) : nullptr, ctx->d_big);
     if (rc) return rc;
     if (acc_host)
         HIPCHK(ctx, hipMemcpyAsync(acc_host, io + acc_off, acc_bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -635,7 +723,7 @@ extern "C" int tfa_keyswitch_batch(tfa_ctx *ctx, const uint32_t *big_in, uint32_
                                  count, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_jobs, jobs.data(), sizeof(KsJob) * count, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    rc = launch_ks(ctx, reinterpret_cast<const KsJob *>(ctx->d_jobs), count, ctx->d_io, ctx->pool_stride);
+    rc = launch_ks(ctx, reinterpret_cast<const KsJob *>(ctx->d_jobs), count, ctx->d_io, ctx->pool_stride, ctx->d_big);
     if (rc) return rc;
     HIPCHK(ctx, hipMemcpy2DAsync(lwe_out, words * sizeof(uint32_t), ctx->d_io, ctx->pool_stride * sizeof(uint32_t), words * sizeof(uint32_t), count,
                                  hipMemcpyDeviceToHost, ctx->stream));

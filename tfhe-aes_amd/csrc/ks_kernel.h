@@ -299,4 +299,12 @@ __global__ void pool_gather_kernel(const uint32_t *__restrict__ pool, uint32_t s
     for (uint32_t w = threadIdx.x; w < words; w += blockDim.x) staging[(size_t)s * words + w] = pool[(size_t)slots[s] * stride + w];
 }
 
+// out[s][0..n] = +-pool[slot][0..n]; bit 31 of slots[s] asks for the LWE negation (ServerKey::not), rows of `out` are dense
+__global__ void pool_export_kernel(const uint32_t *__restrict__ pool, uint32_t stride, const uint32_t *__restrict__ slots, uint32_t *__restrict__ out,
+                                   uint32_t words) {
+    const uint32_t s = blockIdx.x, tagged = slots[s], slot = tagged & 0x7FFFFFFFu;
+    const uint32_t coef = (tagged >> 31) ? 0xFFFFFFFFu : 1u;
+    for (uint32_t w = threadIdx.x; w < words; w += blockDim.x) out[(size_t)s * words + w] = coef * pool[(size_t)slot * stride + w];
+}
+
 }  // namespace tfa

@@ -205,6 +205,15 @@ extern "C" int tfh_state_read(tfh_keys *k, const tfh_state *s, uint32_t *out) {
         for (size_t j = 0; j < cts.size(); j++) std::memcpy(out + pos[j] * words, tmp.data() + j * words, words * sizeof(uint32_t));
     })
 }
+extern "C" int tfh_states_read_device(tfh_keys *k, const tfh_state *const *states, uint32_t n, void *d_out) {
+    TFH_TRY({
+        std::vector<const Ciphertext *> cts;
+        for (uint32_t s = 0; s < n; s++)
+            for (int i = 0; i < 16; i++)
+                for (int b = 0; b < 8; b++) cts.push_back(&states[s]->s.bytes()[i].bit(b));
+        k->kp.server->read_many_device(cts, d_out);
+    })
+}
 extern "C" int tfh_state_import(tfh_keys *k, const uint32_t *lwe, tfh_state **out) {
     TFH_TRY({
         ServerKey &sk = *k->kp.server;

@@ -63,6 +63,7 @@ bool ClientKey::decrypt(const Ciphertext &ct) const {
         if (ct.neg_)
             for (auto &w : words) w = 0u - w;
     } else {
+        if (ct.enc_->slot->alive.expired()) throw std::invalid_argument("decrypt of a ciphertext whose ServerKey is gone");
         words = ct.enc_->slot->owner->read(ct);
     }
     uint8_t bit = 0;
@@ -240,6 +241,31 @@ void ServerKey::read_many(const std::vector<const Ciphertext *> &cts, uint32_t *
     for (size_t i = 0; i < res.size(); i++)
         if (res[i].neg)
             for (uint32_t w = 0; w < words; w++) out[i * words + w] = 0u - out[i * words + w];
+}
+
+void ServerKey::read_many_device(const std::vector<const Ciphertext *> &cts, void *d_out) {
+    const uint32_t words = p_.lwe_dimension + 1;
+    std::vector<Ciphertext> noiseless;  // trivial ciphertexts leave as noiseless encryptions: zero mask, body = +-1/8
+    noiseless.reserve(cts.size());
+    std::vector<Resolved> res;
+    for (auto *c : cts) {
+        if (c->is_trivial()) {
+            std::vector<uint32_t> row(words, 0u);
+            row[words - 1] = c->trivial_value() ? (1u << 29) : (7u << 29);
+            noiseless.push_back(import_lwe(row.data()));
+            res.push_back(resolve(noiseless.back()));
+        } else {
+            res.push_back(resolve(*c));
+        }
+    }
+    flush();
+    std::vector<uint32_t> slots;
+    std::vector<uint8_t> neg;
+    for (auto &r : res) {
+        slots.push_back(r.slot);
+        neg.push_back(r.neg ? 1 : 0);
+    }
+    if (!slots.empty()) check(ctx_, tfa_pool_read_device(ctx_, slots.data(), neg.data(), (uint32_t)slots.size(), d_out), "tfa_pool_read_device");
 }
 
 std::vector<uint32_t> ServerKey::read(const Ciphertext &ct) {

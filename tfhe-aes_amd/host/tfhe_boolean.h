@@ -92,6 +92,7 @@ class ServerKey {
     // LWE words of an encrypted ciphertext (flushes first); used by ClientKey::decrypt and by gathers.
     std::vector<uint32_t> read(const Ciphertext &ct);
     void read_many(const std::vector<const Ciphertext *> &cts, uint32_t *out /*[count][n+1]*/);
+    void read_many_device(const std::vector<const Ciphertext *> &cts, void *d_out /*[count][n+1] on the context's GPU*/);
     Ciphertext import_lwe(const uint32_t *lwe);  // adopt n+1 host words as an encrypted ciphertext
 
     const tfa_params &params() const { return p_; }

@@ -157,6 +157,13 @@ class Context:
         self._chk(self.lib.tfa_pool_read(self._ctx, _u32p(slots), C.c_uint32(slots.size), _u32p(out)), "tfa_pool_read")
         return out
 
+    def pool_read_device(self, slots, device_ptr, negate=None):
+        """Dense rows [len(slots)][n+1] u32 written to device memory at `device_ptr` (an int: e.g. tensor.data_ptr())."""
+        slots = np.ascontiguousarray(slots, np.uint32)
+        neg = np.ascontiguousarray(negate, np.uint8) if negate is not None else None
+        self._chk(self.lib.tfa_pool_read_device(self._ctx, _u32p(slots), _u8p(neg) if neg is not None else None, C.c_uint32(slots.size),
+                                                C.c_void_p(int(device_ptr))), "tfa_pool_read_device")
+
     def stage_submit(self, gates):
         """gates: numpy structured array of GATE_DTYPE (or anything convertible)."""
         gates = np.ascontiguousarray(gates, GATE_DTYPE)

@@ -309,6 +309,16 @@ class State(_Handle):
         return State(keys, h)
 
 
+def read_states_device(states, out):
+    """The 128 LWE ciphertexts of each state, dense, into `out`: a torch int32 CUDA tensor [len(states), 128, n+1] on
+    the ServerKey's GPU (written by the engine on its own stream, complete on return)."""
+    keys = states[0].keys
+    words = keys.params.lwe_dimension + 1
+    assert out.is_cuda and out.is_contiguous() and out.element_size() == 4 and out.numel() >= len(states) * 128 * words
+    _chk(_lib().tfh_states_read_device(keys.h, _handles(states), C.c_uint32(len(states)), C.c_void_p(out.data_ptr())), "tfh_states_read_device")
+    return out
+
+
 def _handles(objs):
     return (C.c_void_p * len(objs))(*[o.h for o in objs])
 
