@@ -121,6 +121,10 @@ def test_key_schedule_online(hkeys):  # key_schedule.rs:220-246 prints; here the
     assert [rk.decrypt_to_u8() for rk in clear] == expected
 
 
+ECB_ENCRYPT_STAGES = 117
+ECB_DECRYPT_STAGES = 144
+
+
 def offline_round_keys(key, hkeys):
     return [H.Key.from_u8_enc(rk, hkeys) for rk in H.key_expansion_clear(key)]
 
@@ -135,8 +139,16 @@ def test_ecb_once(hkeys):  # modes/src/ecb.rs:62-89, FIPS-197 Appendix B
     assert state.decrypt_to_u128() == int(v["ciphertext"], 16)
     after = hkeys.host_stats()
     assert after["gates"] - before["gates"] == 71824
+    # the batch submitter levels the recorded gates by data dependence: 117 stages where the reference's loop
+    # order has 126 (ecb.rs:16-32); the inverse cipher levels to ECB_DECRYPT_STAGES where it has 198 (ecb.rs:34-50,
+    # state.rs:120-215)
+    assert after["stages"] - before["stages"] == ECB_ENCRYPT_STAGES
+    before = after
     ecb.decrypt(state)
     assert state.decrypt_to_u128() == int(v["plaintext"], 16)
+    after = hkeys.host_stats()
+    assert after["gates"] - before["gates"] == 75604
+    assert after["stages"] - before["stages"] == ECB_DECRYPT_STAGES
 
 
 @pytest.mark.timeout(300)
@@ -187,3 +199,56 @@ def test_state_read_import_roundtrip(hkeys):
     assert lwe.shape == (128, hkeys.params.lwe_dimension + 1)
     t = H.State.import_lwe(lwe, hkeys)
     assert t.decrypt_to_u8() == bytes(b ^ 0xFF for b in data)
+
+
+def test_states_read_into_device_memory(hkeys):
+    """tfh_states_read_device: the rows a collective would carry, written on the GPU, equal the host read word for word
+    (negated handles and trivial bits included)."""
+    import torch
+    a = H.State.from_u8_enc(bytes(range(16)), hkeys)
+    b = H.State.from_u8_enc(bytes(range(16, 32)), hkeys)
+    b.xor_key_clear(bytes([0x5A] * 16))           # negation flags on half of the bits
+    a.xor_state(b)                                # bootstrapped outputs
+    out = torch.zeros((2, 128, hkeys.params.lwe_dimension + 1), dtype=torch.int32, device="cuda:0")
+    H.read_states_device([a, b], out)
+    got = out.cpu().numpy().view(np.uint32)
+    assert (got[0] == a.read()).all() and (got[1] == b.read()).all()
+    assert H.State.import_lwe(got[1], hkeys).decrypt_to_u8() == bytes(x ^ 0x5A for x in range(16, 32))
+
+
+@pytest.mark.timeout(900)
+def test_config5_64_ctr_blocks_sharded_over_8_ranks(hkeys):
+    """BASELINE configs[4] on the one GPU at hand: 64 independent CTR blocks (SP 800-38A F.5.1 counters extended),
+    cut by shard.block_partition(64, 8, r) exactly as 8 GPUs would cut them, every rank's 8 blocks run as one batch
+    (ctr.rs:26-35), the shards exported on the device and reassembled in block order; every block against a clear AES,
+    the first four against the standard."""
+    import torch
+    from tfhe_aes_amd import shard
+    v = V["sp800_38a"]
+    key = h(v["key"])
+    rk = offline_round_keys(key, hkeys)
+    c0 = int(v["ctr_init"], 16)
+    rng = np.random.default_rng(64)
+    n_blocks, world = 64, 8
+    pts = [h(v["plaintext"][b]) if b < 4 else rng.integers(0, 256, 16, dtype=np.uint8).tobytes() for b in range(n_blocks)]
+    words = hkeys.params.lwe_dimension + 1
+    shards = []
+    for r in range(world):
+        mine = shard.block_partition(n_blocks, world, r)
+        assert len(mine) == 8
+        counters = [H.State.from_u128_enc((c0 + b) % (1 << 128), hkeys) for b in mine]
+        states = [H.State.from_u8_enc(pts[b], hkeys) for b in mine]
+        before = hkeys.host_stats()["stages"]
+        H.CTR(rk, counters, len(mine)).encrypt(states)
+        local = torch.empty((len(mine), 128, words), dtype=torch.int32, device="cuda:0")
+        H.read_states_device(states, local)
+        assert hkeys.host_stats()["stages"] - before == ECB_ENCRYPT_STAGES + 1   # 8 blocks share the stages; + the final xor
+        shards.append(local)
+    # what all_gather_into_tensor + the reorder of shard.gather_blocks_device produce: rank-major shards -> block order
+    allbuf = torch.cat(shards)
+    b = torch.arange(n_blocks, device="cuda:0")
+    out = allbuf[(b % world) * 8 + b // world].cpu().numpy().view(np.uint32)
+    got = [H.State.import_lwe(out[i], hkeys).decrypt_to_u8() for i in range(n_blocks)]
+    exp = [bytes(x ^ y for x, y in zip(B.aes_encrypt_block(B.key_expansion_clear(key), ((c0 + i) % (1 << 128)).to_bytes(16, "big")), pts[i])) for i in range(n_blocks)]
+    assert got == exp
+    assert [x.hex() for x in got[:4]] == v["ctr"]

@@ -22,6 +22,10 @@ def worker(rank, world, n_blocks, port, ok):
     local = np.stack([fake_block(b) for b in mine]) if mine else np.zeros((0, 128, 6), np.uint32)
     out = shard.gather_blocks(local, n_blocks)
     good = out.shape == (n_blocks, 128, 6) and all((out[b] == fake_block(b)).all() for b in range(n_blocks))
+    # the tensor form the GPUs use (one all_gather_into_tensor, reorder on the device), here on CPU tensors over gloo
+    import torch
+    out_t = shard.gather_blocks_device(torch.from_numpy(local.view(np.int32)), n_blocks)
+    good = good and tuple(out_t.shape) == (n_blocks, 128, 6) and (out_t.numpy().view(np.uint32) == out).all()
     ok[rank] = 1 if good else 0
     dist.barrier()
     dist.destroy_process_group()
@@ -46,3 +50,21 @@ def test_partition_covers_all_blocks():
         parts = [shard.block_partition(n, w, r) for r in range(w)]
         assert sorted(b for p in parts for b in p) == list(range(n))
         assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_bench_launcher_starts_ranks_and_fails_loudly_without_gpus():
+    """`bench.py --gpus 2` with no WORLD_SIZE starts two ranks itself; with no GPU each rank refuses to run (there is no
+    CPU fallback) and the launcher exits non-zero.  A launcher that started a different number of ranks is refused."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert r.stderr.count("needs a GPU") == 2 and "rank exit codes" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr

@@ -41,13 +41,13 @@ def gather_blocks(local, n_blocks, device=None):
 
 
 def gather_blocks_device(local, n_blocks):
-    """The same gather for outputs that are already on the GPU (host.read_states_device): `local` is an int32 CUDA
-    tensor [n_local, ...] in block_partition order; one all_gather_into_tensor (RCCL over xGMI) of the padded shards,
-    then a device-side reorder into global block order.  Returns an int32 CUDA tensor [n_blocks, ...] on every rank."""
+    """The same gather for outputs that are already on the GPU (host.read_states_device): `local` is an int32 tensor
+    [n_local, ...] in block_partition order, on the device of the process group's transport (CUDA under RCCL); one all_gather_into_tensor (RCCL over xGMI) of the padded shards,
+    then a device-side reorder into global block order.  Returns a tensor [n_blocks, ...] on the same device on every rank."""
     world, rank = dist.get_world_size(), dist.get_rank()
     per_rank = (n_blocks + world - 1) // world
     mine = block_partition(n_blocks, world, rank)
-    assert local.is_cuda and local.shape[0] == len(mine), "shard size does not match the partition"
+    assert local.shape[0] == len(mine), "shard size does not match the partition"
     item_shape = tuple(local.shape[1:])
     buf = local
     if len(mine) < per_rank:  # ragged last round: pad the shard for the collective
