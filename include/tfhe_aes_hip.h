@@ -88,6 +88,19 @@ int tfa_pool_device_ptr(tfa_ctx *ctx, void **dptr, uint32_t *stride_words, uint3
 int tfa_stage_submit(tfa_ctx *ctx, const tfa_gate *gates, uint32_t count);
 int tfa_sync(tfa_ctx *ctx);
 
+/* tfa_stage_submit for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc).  No counterpart in the reference.  Same gates, same results, same ordering on the context's stream,
+ * but the stage's job lists and big-LWE intermediates live in a static device array of fixed size instead of the
+ * context's grow-only buffers, and the call performs no hipMalloc / hipFree / hipHostMalloc.  Limits: at most
+ * TFA_NOALLOC_MAX_GATES gates and TFA_NOALLOC_MAX_PBS bootstraps (a MUX counts two) per call; larger stages return
+ * TFA_EINVAL.  Each GPU holds one copy of the array (TFA_NOALLOC_SCRATCH_BYTES) until the process ends; all contexts
+ * on a GPU share it and it keeps the previous call's contents, so calls that overlap on one GPU (two contexts, two
+ * threads) race: serialise them.  The pool must already hold every slot the gates name (tfa_pool_reserve). */
+#define TFA_NOALLOC_MAX_GATES 4096
+#define TFA_NOALLOC_MAX_PBS 4096
+#define TFA_NOALLOC_SCRATCH_BYTES (32u << 20)
+int tfa_stage_submit_noalloc(tfa_ctx *ctx, const tfa_gate *gates, uint32_t count);
+
 /* Building blocks on host buffers (tfhe-rs core_crypto programmable bootstrap / keyswitch as
  * invoked inside every ServerKey gate).  `steps` < n stops the blind rotation early and returns
  * the raw accumulator [count][k+1][N] instead of the extracted LWE. */

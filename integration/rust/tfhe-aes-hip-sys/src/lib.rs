@@ -58,6 +58,9 @@ pub const TFA_MUX: u32 = 6;
 pub const TFA_NOT: u32 = 7;
 pub const TFA_COPY: u32 = 8;
 
+pub const TFA_NOALLOC_MAX_GATES: u32 = 4096;
+pub const TFA_NOALLOC_MAX_PBS: u32 = 4096;
+
 pub const TFA_OK: c_int = 0;
 pub const TFA_EINVAL: c_int = -1;
 pub const TFA_EHIP: c_int = -2;
@@ -78,6 +81,9 @@ extern "C" {
     pub fn tfa_pool_read_device(ctx: *mut tfa_ctx, slots: *const u32, negate: *const u8, count: u32, d_out: *mut c_void) -> c_int;
     pub fn tfa_pool_device_ptr(ctx: *mut tfa_ctx, dptr: *mut *mut c_void, stride_words: *mut u32, n_slots: *mut u32) -> c_int;
     pub fn tfa_stage_submit(ctx: *mut tfa_ctx, gates: *const tfa_gate, count: u32) -> c_int;
+    /// `tfa_stage_submit` on the library's static device scratch: no allocation in the call, at most
+    /// `TFA_NOALLOC_MAX_GATES` gates / `TFA_NOALLOC_MAX_PBS` bootstraps per call.
+    pub fn tfa_stage_submit_noalloc(ctx: *mut tfa_ctx, gates: *const tfa_gate, count: u32) -> c_int;
     pub fn tfa_sync(ctx: *mut tfa_ctx) -> c_int;
     pub fn tfa_bootstrap_batch(ctx: *mut tfa_ctx, lwe_in: *const u32, count: u32, big_out: *mut u32) -> c_int;
     pub fn tfa_blind_rotate_batch(ctx: *mut tfa_ctx, lwe_in: *const u32, count: u32, steps: u32, acc_out: *mut u32) -> c_int;

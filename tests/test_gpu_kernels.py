@@ -289,7 +289,7 @@ def test_stage_hazards_are_rejected(gpu_ctx, oracle, okeys):
     with pytest.raises(E.TfaError, match="another NOT/COPY of the stage reads"):
         gpu_ctx.stage_submit(E.make_gates([E.NOT, E.COPY], [0, 0], [0, 0], None, [0, 9]))      # in place under a second reader
     with pytest.raises(E.TfaError, match="another NOT/COPY of the stage reads"):
-        gpu_ctx.stage_submit(E.make_gates([E.COPY, E.NOT], [1, 2], [0, 0], None, [2, 1]))  # a swap through NOT/COPY
+        gpu_ctx.stage_submit_noalloc(E.make_gates([E.COPY, E.NOT], [1, 2], [0, 0], None, [2, 1]))  # a swap through NOT/COPY
     gpu_ctx.sync()
     assert (gpu_ctx.pool_read(np.arange(12)) == before).all()
     # legal: NOT in place (sole reader), a bootstrapped gate reading a slot that a NOT of the same stage overwrites

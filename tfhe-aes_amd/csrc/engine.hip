@@ -68,6 +68,9 @@ struct tfa_ctx {
     std::vector<uint32_t> slot_mark;
     std::vector<uint64_t> lin_reader;
     uint32_t mark_stamp = 0;
+    // tfa_stage_submit_noalloc: pinned translation buffer of fixed size and the event guarding its reuse
+    unsigned char *h_noalloc = nullptr;
+    hipEvent_t h_noalloc_ev = nullptr;
 };
 
 #define HIPCHK(ctx, call)                                                                                      \
@@ -83,6 +86,7 @@ static int fail(tfa_ctx *ctx, int code, const std::string &msg) {
     ctx->err = msg;
     return code;
 }
+static int noalloc_setup(tfa_ctx *ctx);
 
 static int ensure_io(tfa_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->io_cap) return TFA_OK;
@@ -224,7 +228,7 @@ extern "C" int tfa_ctx_create(const tfa_params *p, int hip_device, tfa_ctx **out
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, PbsGeom<4>::kLdsBytes));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, PbsGeom<8>::kLdsBytes));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bsk_convert_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kConvertLdsBytes));
-    return TFA_OK;
+    return noalloc_setup(ctx);
 }
 
 extern "C" int tfa_ctx_destroy(tfa_ctx *ctx) {
@@ -249,6 +253,8 @@ extern "C" int tfa_ctx_destroy(tfa_ctx *ctx) {
         if (ctx->h_stage[s]) hipHostFree(ctx->h_stage[s]);
         if (ctx->h_stage_ev[s]) hipEventDestroy(ctx->h_stage_ev[s]);
     }
+    if (ctx->h_noalloc) hipHostFree(ctx->h_noalloc);
+    if (ctx->h_noalloc_ev) hipEventDestroy(ctx->h_noalloc_ev);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return TFA_OK;
@@ -649,6 +655,65 @@ extern "C" int tfa_stage_submit(tfa_ctx *ctx, const tfa_gate *gates, uint32_t co
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_jobs, h, L.total, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipEventRecord(ctx->h_stage_ev[slot], ctx->stream));
     rc = stage_launch(ctx, L, ctx->d_jobs, ctx->d_big, true);
+    if (rc) return rc;
+    ctx->stats.gate_count += count;
+    ctx->stats.stage_count++;
+    return TFA_OK;
+}
+
+// ---- the entry point that allocates nothing -----------------------------------------------------
+// Job lists and big-LWE rows of tfa_stage_submit_noalloc live in this file-scope device array instead of the
+// context's grow-only buffers.  Every GPU holds its own copy at its own address (looked up once per device in
+// tfa_ctx_create); all calls on a GPU share it, so calls that overlap on one GPU race.
+static __device__ __align__(256) unsigned char scratch[TFA_NOALLOC_SCRATCH_BYTES];
+namespace {
+constexpr int kMaxDevices = 64;
+unsigned char *g_scratch_ptr[kMaxDevices];  // device address of `scratch` per GPU; the array's name itself is only a host-side handle
+constexpr size_t kNoAllocJobBytes = (sizeof(PbsJob) * TFA_NOALLOC_MAX_PBS + 15) / 16 * 16 + (sizeof(KsJob) * TFA_NOALLOC_MAX_GATES + 15) / 16 * 16 +
+                                    sizeof(LinJob) * TFA_NOALLOC_MAX_GATES;
+constexpr size_t kNoAllocBigOffset = (kNoAllocJobBytes + 255) / 256 * 256;
+constexpr size_t kBigStrideWords = (size_t)(kK1 - 1) * kN + 4;  // big LWE rows: k N + 1 words padded to 16 bytes
+static_assert(kNoAllocBigOffset + (size_t)TFA_NOALLOC_MAX_PBS * kBigStrideWords * sizeof(uint32_t) <= TFA_NOALLOC_SCRATCH_BYTES,
+              "static scratch too small for its stated limits");
+}  // namespace
+
+static int noalloc_setup(tfa_ctx *ctx) {  // tfa_ctx_create, with the context's device current
+    if (ctx->device >= kMaxDevices) return TFA_OK;  // the no-alloc entry point then reports the device as unsupported
+    if (!g_scratch_ptr[ctx->device]) {
+        void *ptr = nullptr;
+        HIPCHK(ctx, hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        g_scratch_ptr[ctx->device] = static_cast<unsigned char *>(ptr);
+    }
+    // translation buffer for the job lists: pinned, fixed size, owned by the context
+    HIPCHK(ctx, hipHostMalloc(&ctx->h_noalloc, kNoAllocJobBytes, hipHostMallocDefault));
+    HIPCHK(ctx, hipEventCreateWithFlags(&ctx->h_noalloc_ev, hipEventDisableTiming));
+    return TFA_OK;
+}
+
+extern "C" int tfa_stage_submit_noalloc(tfa_ctx *ctx, const tfa_gate *gates, uint32_t count) {
+    if (!ctx || (!gates && count)) return TFA_EINVAL;
+    if (count == 0) return TFA_OK;
+    if (!ctx->have_keys) return fail(ctx, TFA_ESTATE, "tfa_stage_submit_noalloc before tfa_keys_upload");
+    if (!ctx->d_pool) return fail(ctx, TFA_ESTATE, "tfa_stage_submit_noalloc before tfa_pool_reserve");
+    if (ctx->device >= kMaxDevices || !g_scratch_ptr[ctx->device] || !ctx->h_noalloc)
+        return fail(ctx, TFA_ESTATE, "static scratch not set up for this device");
+    if (count > TFA_NOALLOC_MAX_GATES)
+        return fail(ctx, TFA_EINVAL, "tfa_stage_submit_noalloc: " + std::to_string(count) + " gates exceed the static scratch (max " +
+                                         std::to_string(TFA_NOALLOC_MAX_GATES) + " gates, " + std::to_string(TFA_NOALLOC_MAX_PBS) + " bootstraps)");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    StageLayout L;
+    int rc = stage_layout(ctx, gates, count, &L);
+    if (rc) return rc;
+    if (L.n_pbs > TFA_NOALLOC_MAX_PBS)
+        return fail(ctx, TFA_EINVAL, "tfa_stage_submit_noalloc: " + std::to_string(L.n_pbs) + " bootstraps exceed the static scratch (max " +
+                                         std::to_string(TFA_NOALLOC_MAX_PBS) + ")");
+    if (ctx->big_stride != kBigStrideWords) return fail(ctx, TFA_ESTATE, "static scratch laid out for another parameter set");
+    unsigned char *dev = g_scratch_ptr[ctx->device];
+    HIPCHK(ctx, hipEventSynchronize(ctx->h_noalloc_ev));  // the previous call's upload has left the translation buffer
+    stage_translate(gates, count, L, ctx->h_noalloc);
+    HIPCHK(ctx, hipMemcpyAsync(dev, ctx->h_noalloc, L.total, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->h_noalloc_ev, ctx->stream));
+    rc = stage_launch(ctx, L, dev, reinterpret_cast<uint32_t *>(dev + kNoAllocBigOffset), false);
     if (rc) return rc;
     ctx->stats.gate_count += count;
     ctx->stats.stage_count++;

@@ -12,6 +12,8 @@ _PKG = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 LIB_PATH = os.environ.get("TFHE_AES_HIP_LIB") or os.path.join(_PKG, "libtfhe_aes_hip.so")
 
 AND, NAND, OR, NOR, XOR, XNOR, MUX, NOT, COPY = range(9)
+NOALLOC_MAX_GATES = 4096   # TFA_NOALLOC_MAX_GATES / TFA_NOALLOC_MAX_PBS of include/tfhe_aes_hip.h
+NOALLOC_MAX_PBS = 4096
 
 
 class Params(C.Structure):
@@ -168,6 +170,12 @@ class Context:
         """gates: numpy structured array of GATE_DTYPE (or anything convertible)."""
         gates = np.ascontiguousarray(gates, GATE_DTYPE)
         self._chk(self.lib.tfa_stage_submit(self._ctx, gates.ctypes.data_as(C.POINTER(Gate)), C.c_uint32(gates.size)), "tfa_stage_submit")
+
+    def stage_submit_noalloc(self, gates):
+        """tfa_stage_submit_noalloc: the same stage on the library's static device scratch (no allocation in the call)."""
+        gates = np.ascontiguousarray(gates, GATE_DTYPE)
+        self._chk(self.lib.tfa_stage_submit_noalloc(self._ctx, gates.ctypes.data_as(C.POINTER(Gate)), C.c_uint32(gates.size)),
+                  "tfa_stage_submit_noalloc")
 
     def sync(self):
         self._chk(self.lib.tfa_sync(self._ctx), "tfa_sync")
