@@ -261,9 +261,32 @@ def launch_ranks(n, argv):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [p.wait() for p in procs]
-    sys.stdout.write(out0)
+    # wait for all of them; when one fails, the others (stuck in the rendezvous or a collective with a dead peer) are
+    # ended by their exact process handles
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    codes = [None] * n
+    while any(c is None for c in codes):
+        for r, pr in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = pr.poll()
+        if any(c not in (None, 0) for c in codes):
+            for r, pr in enumerate(procs):
+                if codes[r] is None:
+                    pr.terminate()
+            for r, pr in enumerate(procs):
+                if codes[r] is None:
+                    try:
+                        codes[r] = pr.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        pr.kill()
+                        codes[r] = pr.wait()
+            break
+        time.sleep(0.2)
+    reader.join(timeout=10)
+    sys.stdout.write("".join(out0))
     sys.stdout.flush()
     if any(codes):
         print(f"[bench] rank exit codes {codes}", file=sys.stderr)

@@ -433,9 +433,16 @@ __device__ __forceinline__ void transpose16(double (&re)[16], double (&im)[16], 
 // holds frequency bins k1 + 16*k2, k2 = 0..15.
 __device__ __forceinline__ void fft_forward(double (&re)[16], double (&im)[16], const c64 *twl, double *tr, int g, int t) {
     dft16_twisted(re, im);
+#ifdef TFA_EXP_NOTWIDDLE  // timing experiment: one twiddle read per transform instead of sixteen (results are garbage)
+    const c64 w0 = twl[t];
+#endif
 #pragma unroll
     for (int k1 = 0; k1 < 16; k1++) {
+#ifdef TFA_EXP_NOTWIDDLE
+        c64 w = w0;
+#else
         c64 w = twl[k1 * 16 + t];
+#endif
         cmulc<1>(re[k1], im[k1], w.x, w.y);
     }
     transpose16(re, im, tr, g, t);
@@ -444,10 +451,17 @@ __device__ __forceinline__ void fft_forward(double (&re)[16], double (&im)[16], 
 // Inverse of fft_forward without the 1/256 (folded into the Fourier key).
 __device__ __forceinline__ void fft_inverse(double (&re)[16], double (&im)[16], const c64 *twl, double *tr, int g, int t) {
     dft16_plain<-1>(re, im);
+#ifdef TFA_EXP_NOTWIDDLE
+    const c64 w0 = twl[t];
+#endif
     transpose16<true>(re, im, tr, g, t);
 #pragma unroll
     for (int k1 = 0; k1 < 16; k1++) {
+#ifdef TFA_EXP_NOTWIDDLE
+        c64 w = w0;
+#else
         c64 w = twl[k1 * 16 + t];
+#endif
         cmulc<-1>(re[k1], im[k1], w.x, w.y);
     }
     dft16_plain<-1>(re, im);
