@@ -13,11 +13,13 @@
 #include "../../include/tfhe_aes_hip.h"
 #include "ks_kernel.h"
 #include "pbs_kernel.h"
+#include "pbs_asm_kernel.h"
 #include "pbs_lat_kernel.h"
 
 using namespace tfa;
 
 namespace {
+constexpr size_t kAsmKeySlackBytes = 131072;  // one blind-rotation step of Fourier key
 constexpr uint32_t kPoolStridePad = 4;   // pool rows padded to a multiple of 4 words (16 B)
 constexpr int kStagingRing = 4;
 
@@ -61,6 +63,7 @@ struct tfa_ctx {
     uint32_t n_cus = 256;
     bool ks_valu = false;  // TFA_KS_VALU=1: keep the keyswitch on the vector ALUs (the generic-parameter path; for comparison)
     bool trace = false;   // TFA_TRACE=1: one stderr line per submitted stage
+    bool pbs_asm = true;  // TFA_PBS_ASM=0: the 8-wave mapping runs the compiler-scheduled kernel instead of the hand-scheduled loop
     int force_waves = 0;  // 0 = choose per launch; 1 / 2 (latency kernel, workgroups per CU), 4 or 8 pins the kernel variant (TFA_PBS_WAVES, for experiments)
     std::vector<EventPair> pending;
     // per-stage validation marks, sized with the pool: slot_mark[s] = stamp of the stage that last wrote s,
@@ -202,6 +205,7 @@ extern "C" int tfa_ctx_create(const tfa_params *p, int hip_device, tfa_ctx **out
     if (prop.multiProcessorCount > 0) ctx->n_cus = (uint32_t)prop.multiProcessorCount;
     if (const char *t = getenv("TFA_TRACE")) ctx->trace = atoi(t) != 0;
     if (const char *t = getenv("TFA_KS_VALU")) ctx->ks_valu = atoi(t) != 0;
+    if (const char *t = getenv("TFA_PBS_ASM")) ctx->pbs_asm = atoi(t) != 0;
     if (const char *w = getenv("TFA_PBS_WAVES")) ctx->force_waves = (atoi(w) == 8 || atoi(w) == 4 || atoi(w) == 2 || atoi(w) == 1) ? atoi(w) : 0;
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     // per-lane twiddles e^{i pi t (1 + 4 r)/512}, [r][t]
@@ -227,6 +231,7 @@ extern "C" int tfa_ctx_create(const tfa_params *p, int hip_device, tfa_ctx **out
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bsk_convert_lat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLatConvertLdsBytes));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, PbsGeom<4>::kLdsBytes));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, PbsGeom<8>::kLdsBytes));
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_asm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PbsGeom<8>::kLdsBytes));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bsk_convert_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kConvertLdsBytes));
     return noalloc_setup(ctx);
 }
@@ -269,7 +274,11 @@ extern "C" int tfa_keys_upload(tfa_ctx *ctx, const uint32_t *bsk, const uint32_t
     const uint64_t bsk_words = tfa_bsk_words(&p);
     const uint32_t n = p.lwe_dimension, kN_ = p.glwe_dimension * p.polynomial_size;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (!ctx->d_bsk_f) HIPCHK(ctx, hipMalloc(&ctx->d_bsk_f, bsk_words / 2 * sizeof(c64)));  // N/2 complex per polynomial
+    // N/2 complex per polynomial, plus one step of slack: the hand-scheduled loop prefetches key chunks without an end-of-key test
+    if (!ctx->d_bsk_f) {
+        HIPCHK(ctx, hipMalloc(&ctx->d_bsk_f, bsk_words / 2 * sizeof(c64) + kAsmKeySlackBytes));
+        HIPCHK(ctx, hipMemset(reinterpret_cast<unsigned char *>(ctx->d_bsk_f) + bsk_words / 2 * sizeof(c64), 0, kAsmKeySlackBytes));
+    }
     if (!ctx->d_bsk_lat) HIPCHK(ctx, hipMalloc(&ctx->d_bsk_lat, bsk_words / 2 * sizeof(c64)));
     if (!ctx->d_ksk) HIPCHK(ctx, hipMalloc(&ctx->d_ksk, (size_t)kN_ * p.ks_level * ctx->ksk_stride * sizeof(uint32_t)));
     // KSK rows padded to the pool stride
@@ -442,7 +451,10 @@ static int launch_pbs(tfa_ctx *ctx, const uint32_t *in_base, uint32_t in_stride,
         const PbsJob *jobs = d_jobs + first;
         uint32_t *big = big_base + (size_t)first * ctx->big_stride;
         uint32_t *acc = acc_out ? acc_out + (size_t)first * kK1 * kN : nullptr;
-        if (variant == 8)
+        if (variant == 8 && ctx->pbs_asm)
+            hipLaunchKernelGGL(pbs_asm_kernel, dim3((count + 7) / 8), dim3(512), PbsGeom<8>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
+                               ctx->d_bsk_f, ctx->d_tw, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
+        else if (variant == 8)
             hipLaunchKernelGGL(pbs_kernel<8>, dim3((count + 7) / 8), dim3(512), PbsGeom<8>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
                                ctx->d_bsk_f, ctx->d_tw, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
         else if (variant == 4)

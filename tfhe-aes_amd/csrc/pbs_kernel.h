@@ -509,6 +509,30 @@ __device__ __forceinline__ void fft_forward_pair_ordered(double (&ar)[16], doubl
     pin16(ar), pin16(ai);
     dft16_plain<1>(br, bi);
 }
+// Two forward transforms on one transpose buffer where each exchange travels behind arithmetic that needs no LDS data:
+// a's exchange behind b's twist and first DFT16 (constants only), b's exchange behind a's second DFT16.  (The LDS
+// returns a wave's reads in order, so a cover that itself waits for LDS reads - b's twiddles - would expose a's exchange.)
+__device__ __forceinline__ void fft_forward_pair_cover(double (&ar)[16], double (&ai)[16], double (&br)[16], double (&bi)[16], const c64 *twl,
+                                                       double *tr, int g, int t) {
+    dft16_twisted(ar, ai);
+#pragma unroll
+    for (int k1 = 0; k1 < 16; k1++) {
+        c64 w = twl[k1 * 16 + t];
+        cmulc<1>(ar[k1], ai[k1], w.x, w.y);
+    }
+    transpose16(ar, ai, tr, g, t);
+    dft16_twisted(br, bi);
+    pin16(br), pin16(bi);  // b's first DFT16 is done (it is a's cover) before b's twiddles are read
+#pragma unroll
+    for (int k1 = 0; k1 < 16; k1++) {
+        c64 w = twl[k1 * 16 + t];
+        cmulc<1>(br[k1], bi[k1], w.x, w.y);
+    }
+    transpose16(br, bi, tr, g, t);
+    dft16_plain<1>(ar, ai);
+    pin16(ar), pin16(ai);
+    dft16_plain<1>(br, bi);
+}
 // Two independent forward transforms interleaved (two transpose buffers): the LDS round trips of one
 // overlap the arithmetic of the other.  Used by the one-wave-per-SIMD variant.
 __device__ __forceinline__ void fft_forward2(double (&ar)[16], double (&ai)[16], double (&br)[16], double (&bi)[16], const c64 *twl, double *trA,
@@ -644,6 +668,76 @@ __device__ __forceinline__ void key_wait_four(v2d &a, v2d &b, v2d &c, v2d &d) {
         asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
     else
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+
+// ---- exchange with pinned reads ------------------------------------------------------------------------------
+// The 16 x 16 exchange of one real plane with the row reads issued as inline asm right behind the stores: the compiler
+// would sink plain loads towards their first use and then wait for them with nothing left to cover the round trip.  It
+// does not count these reads: exchange_wait() must come before the first use of the values.  rd[w] = LDS byte address of
+// this lane's row word holding elements 2w, 2w+1 (tr_load_index), loop invariant.
+struct ExchangeAddr {
+    uint32_t rd[8];
+};
+__device__ __forceinline__ ExchangeAddr exchange_addr(const double *tr, int g, int t) {
+    ExchangeAddr a;
+#pragma unroll
+    for (int w = 0; w < 8; w++) a.rd[w] = lds_offset(tr + g * kTrGroup + tr_load_index(t, 2 * w));
+    return a;
+}
+__device__ __forceinline__ v2d lds_read_b128_ordered(uint32_t addr) {  // after every earlier store of this wave, before every later one
+    v2d v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+// `tie` is a value the covering arithmetic starts from: making the block "modify" it keeps the compiler from starting the
+// cover before the reads are on their way.
+__device__ __forceinline__ void exchange_issue_plane(double (&v)[16], double *tr, int g, int t, const ExchangeAddr &a, double &tie) {
+    double *base = tr + g * kTrGroup;
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 16; r++) base[tr_store_index(r, t)] = v[r];
+    wave_lds_fence();
+    v2d x0, x1, x2, x3, x4, x5, x6, x7;
+    asm volatile(
+        "ds_read_b128 %0, %9\n\tds_read_b128 %1, %10\n\tds_read_b128 %2, %11\n\tds_read_b128 %3, %12\n\t"
+        "ds_read_b128 %4, %13\n\tds_read_b128 %5, %14\n\tds_read_b128 %6, %15\n\tds_read_b128 %7, %16"
+        : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(x4), "=&v"(x5), "=&v"(x6), "=&v"(x7), "+v"(tie)
+        : "v"(a.rd[0]), "v"(a.rd[1]), "v"(a.rd[2]), "v"(a.rd[3]), "v"(a.rd[4]), "v"(a.rd[5]), "v"(a.rd[6]), "v"(a.rd[7])
+        : "memory");
+    v[0] = x0.x, v[1] = x0.y, v[2] = x1.x, v[3] = x1.y, v[4] = x2.x, v[5] = x2.y, v[6] = x3.x, v[7] = x3.y;
+    v[8] = x4.x, v[9] = x4.y, v[10] = x5.x, v[11] = x5.y, v[12] = x6.x, v[13] = x6.y, v[14] = x7.x, v[15] = x7.y;
+}
+__device__ __forceinline__ void exchange_wait(double (&a)[16], double (&b)[16]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]),
+                 "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15]));
+    asm volatile("" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]), "+v"(b[8]), "+v"(b[9]),
+                 "+v"(b[10]), "+v"(b[11]), "+v"(b[12]), "+v"(b[13]), "+v"(b[14]), "+v"(b[15]));
+}
+// Two forward transforms, exchanges issued early and covered by LDS-free arithmetic of the other transform.
+__device__ __forceinline__ void fft_forward_pair_pinned(double (&ar)[16], double (&ai)[16], double (&br)[16], double (&bi)[16], const c64 *twl,
+                                                        double *tr, int g, int t, const ExchangeAddr &xa) {
+    dft16_twisted(ar, ai);
+#pragma unroll
+    for (int k1 = 0; k1 < 16; k1++) {
+        c64 w = twl[k1 * 16 + t];
+        cmulc<1>(ar[k1], ai[k1], w.x, w.y);
+    }
+    exchange_issue_plane(ar, tr, g, t, xa, br[1]);
+    exchange_issue_plane(ai, tr, g, t, xa, bi[1]);
+    dft16_twisted(br, bi);  // cover: constants only
+    pin16(br), pin16(bi);
+    exchange_wait(ar, ai);
+#pragma unroll
+    for (int k1 = 0; k1 < 16; k1++) {
+        c64 w = twl[k1 * 16 + t];
+        cmulc<1>(br[k1], bi[k1], w.x, w.y);
+    }
+    exchange_issue_plane(br, tr, g, t, xa, ar[0]);
+    exchange_issue_plane(bi, tr, g, t, xa, ai[0]);
+    dft16_plain<1>(ar, ai);  // cover
+    pin16(ar), pin16(ai);
+    exchange_wait(br, bi);
+    dft16_plain<1>(br, bi);
 }
 
 // Inverse transform whose sixteen twiddles are read (pinned, uncounted by the compiler) before the first register
@@ -827,6 +921,9 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES * PER_CU / 4)
     if (threadIdx.x < 256) twl[threadIdx.x] = tw[threadIdx.x];
     __syncthreads();
     const uint32_t b_tilde = a_tilde[n];
+#if TFA_FFT_PAIR == 4
+    const ExchangeAddr xaddr = exchange_addr(tr, g, t);
+#endif
 
     // accumulator = X^{-b~} * (0, 0, 0, 2^29 * (1 + X + ... + X^{N-1}))
     uint32_t acc[32];
@@ -927,7 +1024,11 @@ __global__ void __launch_bounds__(WAVES * 64, WAVES * PER_CU / 4)
             // released, so the reads travel behind the remaining products and the row reduction and cost no extra
             // registers.  The reads are inline asm pinned after those products by (unused) operands; the compiler does
             // not count them, so every group starts with an explicit wait.
-#if TFA_FFT_PAIR == 2
+#if TFA_FFT_PAIR == 4
+            fft_forward_pair_pinned(f1r, f1i, f2r, f2i, twl, tr, g, t, xaddr);
+#elif TFA_FFT_PAIR == 3
+            fft_forward_pair_cover(f1r, f1i, f2r, f2i, twl, tr, g, t);
+#elif TFA_FFT_PAIR == 2
             fft_forward_pair_ordered(f1r, f1i, f2r, f2i, twl, tr, g, t);
 #elif TFA_FFT_PAIR
             fft_forward_pair(f1r, f1i, f2r, f2i, twl, tr, g, t);

@@ -1,0 +1,597 @@
+#!/usr/bin/env python3
+"""Generator of the hand-scheduled blind-rotation loop (gfx950 assembly) of pbs_asm_kernel.
+
+Emits tfhe-aes_amd/csrc/pbs_asm_loop.inc: one inline-asm body holding the whole step loop of the 8-wave bootstrap kernel
+(rotation, signed decomposition, two forward negacyclic transforms, multiply-accumulate with the key ring, inverse
+transform, rounding), with every register chosen here and every LDS wait placed by hand.  The arithmetic is that of
+csrc/pbs_kernel.h (same lane mapping, LDS layout, key layout and twiddle table), with the constant twiddle scalings
+folded into fused multiply-adds.  tools/pbs_asm/emu.py executes the emitted text on the CPU against the exact oracle.
+
+Register map (VGPR):  v1 rotation write address | v2 rotation region base | v3 t | v4-7 exchange store addresses |
+v8-11 exchange row-read addresses | v16 twiddle row address | v17 lane*16 | v18 key read address | v19-31 scratch |
+v32-63 accumulator | v64-127 array A (level-1 data, then the output spectrum) | v128-191 array B (level-2 data; the
+inverse transform's twiddles) | v192-223 key words / twiddles / rotated coefficients | v224-255 temporaries.
+v0 and s0-s7 are left to the compiler.  Arrays keep "home slots": element k of array X has its real part in
+X + 2 k and its imaginary part in X + 32 + 2 k; butterflies read their inputs from home slots and write their outputs
+back to the slots they consumed, so only intermediates use the temporaries and no register move is ever needed.
+"""
+import math
+import os
+import sys
+
+# ---- geometry shared with pbs_kernel.h (PbsGeom<8,1>, quad lanes, swizzled exchange buffer) ----
+K_ROT_STRIDE = 520
+K_TR_GROUP = 260
+K_WAVE_LDS = 8320
+K_WAVE_BYTES = 8320 + 1664
+K_TW_OFFSET = 8 * K_WAVE_BYTES
+K_RING_OFFSET = K_TW_OFFSET + 4096
+K_CHUNK_BYTES = 16384
+K_LDS_BYTES = K_RING_OFFSET + 4 * K_CHUNK_BYTES
+STEP_KEY_BYTES = 131072
+MAGIC = 6755399441055744.0  # 1.5 * 2^52
+
+
+def kperm(p):
+    return 4 * (p & 3) + (p >> 2)
+
+
+# ---- scalar registers ----
+S_KP = 8        # s[8:9]  key pointer of the current step for this wave's DMA rows
+S_STEPS = 10    # steps left
+S_ACUR = 11     # LDS byte address of a_tilde[i + 1]
+S_A = 12        # current rotation amount
+S_M0ROW = 13    # LDS byte address of this wave's first DMA row in ring slot 0
+S_TMP = 14      # s[14:15] scratch pair (DMA row pointer)
+S_C2048 = 16
+S_CONST0 = 18   # fp64 constants from here, in pairs
+
+V_ROTWR, V_ROTBASE, V_T = 1, 2, 3
+V_TRWR = [4, 5, 6, 7]            # exchange store address for element groups r >> 2
+V_TRRD = [8, 9, 10, 11]          # exchange row-read address for words (w & 3), offset 64 * (w >> 2)
+V_KBASE = 12                     # LDS base + lane * 16: key words are read at v12 + ring offset
+V_TW, V_LANE16, V_KADDR = 16, 17, 18
+V_AREAD = 19                     # next step's rotation amount (u16 read from LDS)
+V_SCR = list(range(20, 32))      # scratch ints; also v[20:21], v[22:23] as fp64 scratch of the twiddle products
+V_MAGIC = 30                     # v[30:31] = 1.5 * 2^52
+V_ACC = 32
+R_A, R_B, R_K, R_T = 64, 128, 192, 224
+
+INLINE = {1.0: "1.0", 0.5: "0.5", 2.0: "2.0", 4.0: "4.0"}
+
+
+def dreg(r):
+    assert r % 2 == 0
+    return "v[%d:%d]" % (r, r + 1)
+
+
+def qreg(r):
+    assert r % 4 == 0
+    return "v[%d:%d]" % (r, r + 3)
+
+
+class Consts:
+    def __init__(self):
+        self.vals = []
+        self.idx = {}
+
+    def get(self, value):
+        key = float(value)
+        assert key > 0
+        if key not in self.idx:
+            self.idx[key] = len(self.vals)
+            self.vals.append(key)
+        r = S_CONST0 + 2 * self.idx[key]
+        assert r + 1 <= 101, "out of scalar registers for constants"
+        return "s[%d:%d]" % (r, r + 1)
+
+
+class V:
+    """A double in an even-aligned VGPR pair with a pending sign; `temp` marks registers owned by the temporary pool."""
+    __slots__ = ("reg", "neg", "temp")
+
+    def __init__(self, reg, neg=False, temp=False):
+        self.reg, self.neg, self.temp = reg, neg, temp
+
+    def __neg__(self):
+        return V(self.reg, not self.neg, self.temp)
+
+    def s(self, flip=False):
+        return ("-" if (self.neg != flip) else "") + dreg(self.reg)
+
+
+class C:
+    __slots__ = ("r", "i")
+
+    def __init__(self, r, i):
+        self.r, self.i = r, i
+
+    def times_i(self, s):      # multiply by s * i, s = +-1: renaming only
+        return C(-self.i, self.r) if s > 0 else C(self.i, -self.r)
+
+
+class Pool:
+    def __init__(self, regs):
+        self.free = list(regs)
+        self.low_water = len(self.free)
+
+    def get(self):
+        assert self.free, "temporary pool exhausted"
+        r = self.free.pop(0)
+        self.low_water = min(self.low_water, len(self.free))
+        return r
+
+    def put(self, reg):
+        assert reg not in self.free
+        self.free.append(reg)
+
+
+class Stream:
+    def __init__(self, gen, pool):
+        self.g, self.pool, self.ins = gen, pool, []
+
+    def e(self, s):
+        self.ins.append(s)
+
+    def cst(self, val):
+        val = float(val)
+        return INLINE[val] if val in INLINE else self.g.consts.get(val)
+
+    def _dst(self, dst):
+        if dst is None:
+            return V(self.pool.get(), temp=True)
+        return V(dst)
+
+    def kill(self, *vs):
+        for v in vs:
+            if v.temp:
+                self.pool.put(v.reg)
+
+    def add(self, a, b, dst=None):
+        d = self._dst(dst)
+        self.e("v_add_f64 %s, %s, %s" % (dreg(d.reg), a.s(), b.s()))
+        return d
+
+    def mul(self, a, b, dst=None):
+        d = self._dst(dst)
+        self.e("v_mul_f64 %s, %s, %s" % (dreg(d.reg), a.s(), b.s()))
+        return d
+
+    def mulc(self, a, cval, dst=None):
+        d = self._dst(dst)
+        self.e("v_mul_f64 %s, %s, %s" % (dreg(d.reg), a.s(flip=cval < 0), self.cst(abs(cval))))
+        return d
+
+    def fma(self, a, b, c, dst=None):
+        d = self._dst(dst)
+        self.e("v_fma_f64 %s, %s, %s, %s" % (dreg(d.reg), a.s(), b.s(), c.s()))
+        return d
+
+    def fmac(self, cval, b, c, dst=None):   # cval * b + c
+        if abs(cval) == 1.0:
+            return self.add(b if cval > 0 else -b, c, dst)
+        d = self._dst(dst)
+        self.e("v_fma_f64 %s, %s, %s, %s" % (dreg(d.reg), b.s(flip=cval < 0), self.cst(abs(cval)), c.s()))
+        return d
+
+
+def rot_tan(st, z, tau, S):
+    """z * (1 + i S tau); the imaginary part stays in place, the real part moves to a temporary"""
+    t = tau if S > 0 else -tau
+    nr = st.fmac(-t, z.i, z.r)
+    ni = st.fmac(t, z.r, z.i, dst=(None if z.i.temp else z.i.reg))
+    if z.i.temp:
+        st.kill(z.i)
+    st.kill(z.r)
+    return C(nr, ni)
+
+
+def dft4(st, z, S, out):
+    """out: four (re_reg, im_reg) destinations (the home slots of the positions consumed)"""
+    z0, z1, z2, z3 = z
+    t0 = C(st.add(z0.r, z2.r), st.add(z0.i, z2.i))
+    t1 = C(st.add(z0.r, -z2.r), st.add(z0.i, -z2.i))
+    st.kill(z0.r, z0.i, z2.r, z2.i)
+    t2 = C(st.add(z1.r, z3.r), st.add(z1.i, z3.i))
+    d = C(st.add(z1.r, -z3.r), st.add(z1.i, -z3.i))
+    st.kill(z1.r, z1.i, z3.r, z3.i)
+    t3 = d.times_i(S)
+    o0 = C(st.add(t0.r, t2.r, out[0][0]), st.add(t0.i, t2.i, out[0][1]))
+    o2 = C(st.add(t0.r, -t2.r, out[2][0]), st.add(t0.i, -t2.i, out[2][1]))
+    st.kill(t0.r, t0.i, t2.r, t2.i)
+    o1 = C(st.add(t1.r, t3.r, out[1][0]), st.add(t1.i, t3.i, out[1][1]))
+    o3 = C(st.add(t1.r, -t3.r, out[3][0]), st.add(t1.i, -t3.i, out[3][1]))
+    st.kill(t1.r, t1.i, d.r, d.i)
+    return [o0, o1, o2, o3]
+
+
+def dft4_scaled(st, z, c1, c2, q, S, out, c0=None):
+    """DFT4 of (c0) z0, c1 z1, c2 z2, c3 z3 with q = c3 / c1; the scalings ride on the multiply-adds."""
+    z0, z1, z2, z3 = z
+    if c0 is not None and c0 != 1.0:
+        nr, ni = st.mulc(z0.r, c0), st.mulc(z0.i, c0)
+        st.kill(z0.r, z0.i)
+        z0 = C(nr, ni)
+    t0 = C(st.fmac(c2, z2.r, z0.r), st.fmac(c2, z2.i, z0.i))
+    t1 = C(st.fmac(-c2, z2.r, z0.r), st.fmac(-c2, z2.i, z0.i))
+    st.kill(z0.r, z0.i, z2.r, z2.i)
+    t2 = C(st.fmac(q, z3.r, z1.r), st.fmac(q, z3.i, z1.i))
+    d = C(st.fmac(-q, z3.r, z1.r), st.fmac(-q, z3.i, z1.i))
+    st.kill(z1.r, z1.i, z3.r, z3.i)
+    o0 = C(st.fmac(c1, t2.r, t0.r, out[0][0]), st.fmac(c1, t2.i, t0.i, out[0][1]))
+    o2 = C(st.fmac(-c1, t2.r, t0.r, out[2][0]), st.fmac(-c1, t2.i, t0.i, out[2][1]))
+    st.kill(t0.r, t0.i, t2.r, t2.i)
+    sc = c1 if S > 0 else -c1
+    o1 = C(st.fmac(-sc, d.i, t1.r, out[1][0]), st.fmac(sc, d.r, t1.i, out[1][1]))       # t1 + S i c1 d
+    o3 = C(st.fmac(sc, d.i, t1.r, out[3][0]), st.fmac(-sc, d.r, t1.i, out[3][1]))
+    st.kill(t1.r, t1.i, d.r, d.i)
+    return [o0, o1, o2, o3]
+
+
+C1, S1, R = 0.9238795325112867, 0.3826834323650898, 0.7071067811865476
+T1, T3 = S1 / C1, C1 / S1
+KC32 = [math.cos(math.pi * n / 32) for n in range(16)]
+KS32 = [math.sin(math.pi * n / 32) for n in range(16)]
+
+
+class Arr:
+    """A complex array of 16 in home slots of region `base`; pos[k] = slot holding logical element k."""
+
+    def __init__(self, base):
+        self.base = base
+        self.pos = list(range(16))
+
+    def slot(self, p):
+        return (self.base + 2 * p, self.base + 32 + 2 * p)
+
+    def val(self, k):
+        r, i = self.slot(self.pos[k])
+        return C(V(r), V(i))
+
+
+class Loop:
+    def __init__(self):
+        self.consts = Consts()
+        self.out = []
+        self.pool = Pool(range(R_T, R_T + 32, 2))
+
+    def e(self, s):
+        self.out.append(s)
+
+    def lds_wait(self, n):
+        self.e("s_waitcnt lgkmcnt(%d)" % n)
+
+    # ---- register DFT16 in place (port of dft16m of pbs_kernel.h) ---------------------------------------------------
+    def dft16(self, X, S, twist):
+        """Transforms array X over its logical index; afterwards logical output k sits in slot 4 (k & 3) + (k >> 2) of
+        the slots the inputs occupied."""
+        st = Stream(self, self.pool)
+        inp = [X.val(k) for k in range(16)]
+        slots = [X.slot(X.pos[k]) for k in range(16)]    # slot of logical input k
+        u = [None] * 16                                  # u[4 k1 + n2], with the slot it lives in
+        uslot = [None] * 16
+        for n2 in range(4):
+            ns = [n2, 4 + n2, 8 + n2, 12 + n2]
+            grp = [inp[n] for n in ns]
+            outs = [slots[n] for n in ns]
+            if not twist:
+                o = dft4(st, grp, S, outs)
+            else:
+                grp = [rot_tan(st, grp[k], KS32[ns[k]] / KC32[ns[k]], 1) if ns[k] > 0 else grp[k] for k in range(4)]
+                o = dft4_scaled(st, grp, KC32[4 + n2], KC32[8 + n2], KC32[12 + n2] / KC32[4 + n2], 1, outs, c0=(KC32[n2] if n2 > 0 else None))
+            for k1 in range(4):
+                u[4 * k1 + n2] = o[k1]
+                uslot[4 * k1 + n2] = outs[k1]
+        newpos = [None] * 16
+
+        def place(k1, o, outs):
+            for k2 in range(4):
+                k = k1 + 4 * k2
+                r, _ = outs[k2]
+                newpos[k] = (r - X.base) // 2
+        # k1 = 0
+        outs = uslot[0:4]
+        place(0, dft4(st, u[0:4], S, outs), outs)
+        # k1 = 1: e = 1, 2, 3
+        outs = uslot[4:8]
+        g = [u[4], rot_tan(st, u[5], T1, S), rot_tan(st, u[6], 1.0, S), rot_tan(st, u[7], T3, S)]
+        place(1, dft4_scaled(st, g, C1, R, S1 / C1, S, outs), outs)
+        # k1 = 2: e = 2, 4 (a quarter turn), 6
+        outs = uslot[8:12]
+        g = [u[8], rot_tan(st, u[9], 1.0, S), u[10].times_i(S), rot_tan(st, u[11], -1.0, S)]
+        place(2, dft4_scaled(st, g, R, 1.0, -1.0, S, outs), outs)
+        # k1 = 3: e = 3, 6, 9
+        outs = uslot[12:16]
+        g = [u[12], rot_tan(st, u[13], T3, S), rot_tan(st, u[14], -1.0, S), rot_tan(st, u[15], T1, S)]
+        place(3, dft4_scaled(st, g, S1, -R, -C1 / S1, S, outs), outs)
+        X.pos = newpos
+        assert sorted(newpos) == list(range(16))
+        assert len(self.pool.free) == 16, "temporaries leaked"
+        self.out.extend(st.ins)
+
+    # ---- rotation + decomposition -------------------------------------------------------------------------------------
+    def rotate_decompose(self):
+        """d = acc * X^a - acc, both digits of every coefficient as doubles: level 1 -> array A, level 2 -> array B
+        (element n1 real part = coefficient 16 n1 + t, imaginary part = coefficient 16 n1 + t + 256).  The accumulator
+        already sits in the rotation buffer (written by the previous step's tail, or by the prologue)."""
+        e = self.e
+        vb, x, ad = V_SCR[0], V_SCR[1], V_SCR[2]
+        e("v_subrev_u32 v%d, s%d, v%d" % (vb, S_A, V_T))                # t - a
+        for m in range(32):
+            e("v_add_u32 v%d, %d, v%d" % (x, 16 * m, vb))
+            e("v_and_b32 v%d, 0x1ff, v%d" % (ad, x))
+            e("v_lshl_add_u32 v%d, v%d, 2, v%d" % (ad, ad, V_ROTBASE))
+            e("ds_read_b32 v%d, v%d" % (R_K + m, ad))
+        # the m-th read has returned when at most 31 - m younger ones are in flight (the counter saturates at 15)
+        sg, ng, y, s_, u, w = V_SCR[3], V_SCR[4], V_SCR[5], V_SCR[6], V_SCR[7], V_SCR[8]
+        for m in range(32):
+            self.lds_wait(min(15, 31 - m))
+            v = R_K + m
+            e("v_add_u32 v%d, %d, v%d" % (x, 16 * m, vb))
+            e("v_bfe_i32 v%d, v%d, 9, 1" % (sg, x))                      # 0 or ~0: X^N = -1
+            e("v_bfe_u32 v%d, v%d, 9, 1" % (ng, x))                      # 0 or 1 = -sg
+            e("v_xor_b32 v%d, v%d, v%d" % (y, v, sg))
+            e("v_sub_u32 v%d, v%d, v%d" % (ng, ng, V_ACC + m))           # -sg - acc
+            e("v_add3_u32 v%d, v%d, v%d, s%d" % (y, y, ng, S_C2048))      # y = sign * v - acc + 2^11
+            e("v_lshrrev_b32 v%d, 12, v%d" % (s_, y))
+            e("v_lshrrev_b32 v%d, 31, v%d" % (u, y))
+            e("v_add_u32 v%d, v%d, v%d" % (u, s_, u))                    # s + bit 19 of the state
+            e("v_add_u32 v%d, 0x7fdff, v%d" % (w, u))
+            e("v_bfe_u32 v%d, v%d, 10, 10" % (w, w))
+            e("v_add_u32 v%d, 0xfffffe01, v%d" % (w, w))                 # d1
+            e("v_cvt_f64_i32 %s, v%d" % (dreg(R_A + 2 * m), w))
+            e("v_add_u32 v%d, 0x1ff, v%d" % (u, u))
+            e("v_and_b32 v%d, 0xfffffc00, v%d" % (u, u))
+            e("v_sub_u32 v%d, v%d, v%d" % (u, s_, u))                    # d2
+            e("v_cvt_f64_i32 %s, v%d" % (dreg(R_B + 2 * m), u))
+
+    # ---- twiddles -------------------------------------------------------------------------------------------------------
+    def tw_issue(self, k0, count, region):
+        for k in range(count):
+            self.e("ds_read_b128 %s, v%d offset:%d" % (qreg(region + 4 * k), V_TW, (k0 + k) * 256))
+
+    def tw_mul(self, X, k0, count, region, S):
+        """X[k0 .. k0+count) *= (c + i S s) in place, entry j of `region` = (c, s) of element k0 + j"""
+        e = self.e
+        m1, m2 = V(V_SCR[0]), V(V_SCR[2])
+        for j in range(count):
+            c, s = V(region + 4 * j), V(region + 4 * j + 2)
+            z = X.val(k0 + j)
+            e("v_mul_f64 %s, %s, %s" % (dreg(m1.reg), z.i.s(), s.s()))
+            e("v_mul_f64 %s, %s, %s" % (dreg(m2.reg), z.r.s(), s.s()))
+            e("v_fma_f64 %s, %s, %s, %s" % (dreg(z.r.reg), z.r.s(), c.s(), m1.s(flip=S > 0)))
+            e("v_fma_f64 %s, %s, %s, %s" % (dreg(z.i.reg), z.i.s(), c.s(), m2.s(flip=S < 0)))
+
+    # ---- exchange -------------------------------------------------------------------------------------------------------
+    def exchange_plane(self, X, plane):
+        """16 x 16 exchange of one real plane: element r of this lane -> [r][t], row t back into the home slots in
+        natural order.  Only issues; the caller waits."""
+        for r in range(16):
+            reg = X.slot(X.pos[r])[plane]
+            self.e("ds_write_b64 v%d, %s offset:%d" % (V_TRWR[r >> 2], dreg(reg), r * 128))
+        base = X.base + 32 * plane
+        for w in range(8):
+            self.e("ds_read_b128 %s, v%d offset:%d" % (qreg(base + 4 * w), V_TRRD[w & 3], 64 * (w >> 2)))
+
+    def exchange(self, X):
+        self.exchange_plane(X, 0)
+        self.exchange_plane(X, 1)
+        X.pos = list(range(16))
+
+    # ---- key ring ---------------------------------------------------------------------------------------------------------
+    def acquire(self, q):
+        """chunk q of the current step: own DMA rows landed, barrier, refill the slot freed by the previous chunk with
+        chunk q + 3 (the key buffer is padded, so the prefetch needs no end-of-key test), key read address of chunk q"""
+        e = self.e
+        e("s_waitcnt vmcnt(4)")
+        e("s_barrier")
+        qq = q + 3
+        off = qq * 8192 if qq < 8 else STEP_KEY_BYTES + (qq - 8) * 8192
+        slot = qq % 4
+        e("s_add_u32 s%d, s%d, 0x%x" % (S_TMP, S_KP, off))
+        e("s_addc_u32 s%d, s%d, 0" % (S_TMP + 1, S_KP + 1))
+        e("s_add_u32 m0, s%d, 0x%x" % (S_M0ROW, slot * K_CHUNK_BYTES))
+        e("s_nop 0")
+        e("global_load_lds_dwordx4 v%d, s[%d:%d]" % (V_LANE16, S_TMP, S_TMP + 1))
+        e("s_add_u32 s%d, s%d, 0x400" % (S_TMP, S_TMP))
+        e("s_addc_u32 s%d, s%d, 0" % (S_TMP + 1, S_TMP + 1))
+        e("s_add_u32 m0, s%d, 0x%x" % (S_M0ROW, slot * K_CHUNK_BYTES + 1024))
+        e("s_nop 0")
+        e("global_load_lds_dwordx4 v%d, s[%d:%d]" % (V_LANE16, S_TMP, S_TMP + 1))
+        e("v_add_u32 v%d, 0x%x, v%d" % (V_KADDR, K_RING_OFFSET + (q % 4) * K_CHUNK_BYTES, V_KBASE))
+
+    def key_issue(self, pos, pair):
+        """key words of frequency position `pos`, columns 2 pair and 2 pair + 1, both levels"""
+        kk = pos % 2
+        for c in (2 * pair, 2 * pair + 1):
+            for lv in (0, 1):
+                self.e("ds_read_b128 %s, v%d offset:%d" % (qreg(R_K + 16 * lv + 4 * c), V_KADDR, (kk * 8 + lv * 4 + c) * 1024))
+
+    def mac(self, A, B):
+        """A[k2] <- sum over polynomials and levels of spectrum x key, for all 16 frequency groups (in key order)"""
+        e = self.e
+        T = [R_T + 2 * j for j in range(8)]          # pr[0..3], pi[0..3]
+        pr, pi = T[0:4], T[4:8]
+        self.acquire(0)
+        self.key_issue(0, 0)
+        self.key_issue(0, 1)
+        for pos in range(16):
+            k2 = kperm(pos)
+            more = pos + 1 < 16
+            opens = more and (pos + 1) % 2 == 0
+            f1, f2 = A.val(k2), B.val(k2)
+            if opens:
+                self.lds_wait(0)          # the whole chunk is in registers before the barrier that lets it be refilled
+                self.acquire((pos + 1) // 2)
+            for pair in (0, 1):
+                if not opens:
+                    self.lds_wait(4 if (pair == 0 or more) else 0)
+                cols = (2 * pair, 2 * pair + 1)
+                b0 = {c: (V(R_K + 4 * c), V(R_K + 4 * c + 2)) for c in cols}
+                b1 = {c: (V(R_K + 16 + 4 * c), V(R_K + 16 + 4 * c + 2)) for c in cols}
+                seq = [[] for _ in range(4)]         # four independent accumulation chains, interleaved
+                for n, c in enumerate(cols):
+                    x0, y0 = b0[c]
+                    x1, y1 = b1[c]
+                    seq[2 * n] = ["v_mul_f64 %s, %s, %s" % (dreg(pr[c]), f1.r.s(), x0.s()),
+                                  "v_fma_f64 %s, %s, %s, %s" % (dreg(pr[c]), f1.i.s(flip=True), y0.s(), dreg(pr[c])),
+                                  "v_fma_f64 %s, %s, %s, %s" % (dreg(pr[c]), f2.r.s(), x1.s(), dreg(pr[c])),
+                                  "v_fma_f64 %s, %s, %s, %s" % (dreg(pr[c]), f2.i.s(flip=True), y1.s(), dreg(pr[c]))]
+                    seq[2 * n + 1] = ["v_mul_f64 %s, %s, %s" % (dreg(pi[c]), f1.r.s(), y0.s()),
+                                      "v_fma_f64 %s, %s, %s, %s" % (dreg(pi[c]), f1.i.s(), x0.s(), dreg(pi[c])),
+                                      "v_fma_f64 %s, %s, %s, %s" % (dreg(pi[c]), f2.r.s(), y1.s(), dreg(pi[c])),
+                                      "v_fma_f64 %s, %s, %s, %s" % (dreg(pi[c]), f2.i.s(), x1.s(), dreg(pi[c]))]
+                for step in range(4):
+                    for ch in range(4):
+                        e(seq[ch][step])
+                if more:
+                    self.key_issue(pos + 1, pair)
+            # sum over the four polynomials of the quad, scattered so that lane g ends with output polynomial g:
+            # lane g's p[j] belongs to output j ^ g.  Two values from the neighbour at distance 2, one at distance 1.
+            def dpp(reg, ctrl):
+                for h in (0, 1):
+                    e("v_mov_b32_dpp v%d, v%d quad_perm:%s row_mask:0xf bank_mask:0xf" % (reg + h, reg + h, ctrl))
+            X2, X1 = "[2,3,0,1]", "[1,0,3,2]"
+            dpp(pr[2], X2)
+            dpp(pi[2], X2)
+            dpp(pr[3], X2)
+            dpp(pi[3], X2)
+            e("v_add_f64 %s, %s, %s" % (dreg(pr[0]), dreg(pr[0]), dreg(pr[2])))     # sa (real)
+            e("v_add_f64 %s, %s, %s" % (dreg(pr[1]), dreg(pr[1]), dreg(pr[3])))     # sb (real)
+            e("v_add_f64 %s, %s, %s" % (dreg(pi[0]), dreg(pi[0]), dreg(pi[2])))
+            e("v_add_f64 %s, %s, %s" % (dreg(pi[1]), dreg(pi[1]), dreg(pi[3])))
+            e("s_nop 1")
+            dpp(pr[1], X1)
+            dpp(pi[1], X1)
+            orr, oi = A.slot(A.pos[k2])
+            e("v_add_f64 %s, %s, %s" % (dreg(orr), dreg(pr[0]), dreg(pr[1])))
+            e("v_add_f64 %s, %s, %s" % (dreg(oi), dreg(pi[0]), dreg(pi[1])))
+
+    # ---- the step ---------------------------------------------------------------------------------------------------------
+    def step(self):
+        e = self.e
+        A, B = Arr(R_A), Arr(R_B)
+        self.rotate_decompose()
+        # forward transform of the level-1 digits; its exchange travels behind the first half of the level-2 transform
+        self.tw_issue(0, 8, R_K)
+        self.dft16(A, 1, True)
+        self.tw_issue(8, 8, R_T)
+        self.lds_wait(8)
+        self.tw_mul(A, 0, 8, R_K, 1)
+        self.lds_wait(0)
+        self.tw_mul(A, 8, 8, R_T, 1)
+        self.exchange(A)
+        self.tw_issue(0, 8, R_K)
+        self.dft16(B, 1, True)
+        self.tw_issue(8, 8, R_T)
+        self.lds_wait(8)               # A's exchange and the first eight twiddles are in
+        self.tw_mul(B, 0, 8, R_K, 1)
+        self.lds_wait(0)
+        self.tw_mul(B, 8, 8, R_T, 1)
+        self.exchange(B)
+        self.dft16(A, 1, False)        # cover for B's exchange
+        self.lds_wait(0)
+        self.dft16(B, 1, False)
+        # spectrum x key
+        self.mac(A, B)
+        # inverse transform of the sums (array A); array B is free and holds all sixteen twiddles
+        e("v_mov_b32 v%d, s%d" % (V_SCR[0], S_ACUR))
+        e("ds_read_u16 v%d, v%d" % (V_AREAD, V_SCR[0]))
+        self.tw_issue(0, 16, R_B)
+        self.dft16(A, -1, False)
+        self.exchange(A)
+        self.lds_wait(0)
+        e("v_readfirstlane_b32 s%d, v%d" % (S_A, V_AREAD))
+        self.tw_mul(A, 0, 16, R_B, -1)
+        self.dft16(A, -1, False)
+        # untwist by e^{-i pi n1 / 32}, round to the torus, accumulate, and put the new accumulator into the rotation buffer
+        st = Stream(self, self.pool)
+        magic = V(V_MAGIC)
+        for n1 in range(16):
+            z = A.val(n1)
+            if n1 == 0:
+                rr, ri = st.add(z.r, magic), st.add(z.i, magic)
+            else:
+                tau, c = KS32[n1] / KC32[n1], KC32[n1]
+                nr = st.fmac(tau, z.i, z.r)          # (r + i i)(1 - i tau)
+                ni = st.fmac(-tau, z.r, z.i)
+                # round(c x) as an integer in the low mantissa word: one multiply-add with 1.5 * 2^52
+                rr, ri = st.fmac(c, nr, magic), st.fmac(c, ni, magic)
+                st.kill(nr, ni)
+            for (val, m) in ((rr, n1), (ri, 16 + n1)):
+                st.e("v_add_u32 v%d, v%d, v%d" % (V_ACC + m, V_ACC + m, val.reg))
+                st.e("ds_write_b32 v%d, v%d offset:%d" % (V_ROTWR, V_ACC + m, 64 * m))
+            st.kill(rr, ri)
+        self.out.extend(st.ins)
+        assert len(self.pool.free) == 16
+
+    def build(self):
+        e = self.e
+        body = Loop.__new__(Loop)
+        body.consts, body.out, body.pool = self.consts, [], self.pool
+        body.step()
+        # constants (known only after the body has been generated)
+        import struct
+        e("s_mov_b32 s%d, 0x800" % S_C2048)
+        for j, val in enumerate(self.consts.vals):
+            bits = struct.unpack("<Q", struct.pack("<d", val))[0]
+            e("s_mov_b32 s%d, 0x%x" % (S_CONST0 + 2 * j, bits & 0xFFFFFFFF))
+            e("s_mov_b32 s%d, 0x%x" % (S_CONST0 + 2 * j + 1, bits >> 32))
+        mbits = struct.unpack("<Q", struct.pack("<d", MAGIC))[0]
+        e("v_mov_b32 v%d, 0x%x" % (V_MAGIC, mbits & 0xFFFFFFFF))
+        e("v_mov_b32 v%d, 0x%x" % (V_MAGIC + 1, mbits >> 32))
+        e("L_step%=:")
+        self.out.extend(body.out)
+        e("s_add_u32 s%d, s%d, 0x%x" % (S_KP, S_KP, STEP_KEY_BYTES))
+        e("s_addc_u32 s%d, s%d, 0" % (S_KP + 1, S_KP + 1))
+        e("s_add_u32 s%d, s%d, 2" % (S_ACUR, S_ACUR))
+        e("s_sub_u32 s%d, s%d, 1" % (S_STEPS, S_STEPS))
+        e("s_cmp_lg_u32 s%d, 0" % S_STEPS)
+        e("s_cbranch_scc1 L_step%=")
+        e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        return self.out
+
+
+def clobbers(lines):
+    import re
+    v, s = set(), set()
+    for ln in lines:
+        for m in re.finditer(r"\bv\[(\d+):(\d+)\]", ln):
+            v.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        for m in re.finditer(r"\bv(\d+)\b", ln):
+            v.add(int(m.group(1)))
+        for m in re.finditer(r"\bs\[(\d+):(\d+)\]", ln):
+            s.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        for m in re.finditer(r"\bs(\d+)\b", ln):
+            s.add(int(m.group(1)))
+    return sorted(v), sorted(s)
+
+
+def main():
+    g = Loop()
+    lines = g.build()
+    v, s = clobbers(lines)
+    inputs_v = set([V_ROTWR, V_ROTBASE, V_T] + V_TRWR + V_TRRD + [V_KBASE, V_TW, V_LANE16]) | set(range(V_ACC, V_ACC + 32))
+    inputs_s = set([S_KP, S_KP + 1, S_STEPS, S_ACUR, S_A, S_M0ROW])
+    assert 0 not in v and not (set(range(0, 8)) & set(s)), "v0 / s0-s7 belong to the compiler"
+    cl = ['"v%d"' % r for r in v if r not in inputs_v] + ['"s%d"' % r for r in s if r not in inputs_s]
+    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tfhe-aes_amd", "csrc", "pbs_asm_loop.inc")
+    with open(out_path, "w") as f:
+        f.write("// GENERATED by tools/pbs_asm/gen.py - do not edit.  %d instructions per blind-rotation step.\n" % len([x for x in lines if not x.endswith(":")]))
+        f.write("#define TFA_PBS_ASM_BODY \\\n")
+        for ln in lines:
+            f.write('    "%s\\n\\t" \\\n' % ln)
+        f.write('    ""\n')
+        f.write("#define TFA_PBS_ASM_CLOBBERS %s\n" % ", ".join(cl + ['"memory"', '"scc"', '"vcc"']))
+    stats = {}
+    for ln in lines:
+        op = ln.split()[0]
+        stats[op] = stats.get(op, 0) + 1
+    valu = sum(n for op, n in stats.items() if op.startswith("v_"))
+    print("lines", len(lines), "VALU", valu, "f64", sum(n for op, n in stats.items() if "f64" in op), "ds", sum(n for op, n in stats.items() if op.startswith("ds_")),
+          "consts", len(g.consts.vals), "temp low water", g.pool.low_water)
+    return lines
+
+
+if __name__ == "__main__":
+    main()
