@@ -1,0 +1,12 @@
+//! `base` of pjanthony2001/tfhe-aes with its gate calls routed to the MI355X engine.
+//! `boolean_tree`, `sbox` and `key_schedule` are the reference's own modules (see README.md).
+pub mod boolean_tree;
+pub mod hip;
+pub mod key_schedule;
+pub mod primitive;
+pub mod sbox;
+pub mod state;
+
+pub use key_schedule::Key;
+pub use primitive::FHEByte;
+pub use state::State;

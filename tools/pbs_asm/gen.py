@@ -567,9 +567,38 @@ def clobbers(lines):
     return sorted(v), sorted(s)
 
 
+def experiment_filter(lines, flags):
+    """Timing experiments (results become garbage): drop classes of instructions from the emitted loop.
+    nolds: every ds_* instruction; nokey / notw / noexch / norot: the key, twiddle, exchange, rotation LDS traffic; nowait: the LDS waits; nobar: the barriers; nodma: the ring's LDS-DMA and its waits."""
+    out = []
+    for ln in lines:
+        op = ln.split()[0]
+        if "nolds" in flags and op.startswith("ds_"):
+            continue
+        if "nokey" in flags and op == "ds_read_b128" and ", v%d " % V_KADDR in ln:
+            continue
+        if "notw" in flags and op == "ds_read_b128" and ", v%d " % V_TW in ln:
+            continue
+        if "noexch" in flags and (op == "ds_write_b64" or (op == "ds_read_b128" and any(", v%d " % r in ln for r in V_TRRD))):
+            continue
+        if "norot" in flags and op in ("ds_read_b32", "ds_write_b32"):
+            continue
+        if "nowait" in flags and op == "s_waitcnt" and "lgkmcnt" in ln and "vmcnt" not in ln:
+            continue
+        if "nobar" in flags and op == "s_barrier":
+            continue
+        if "nodma" in flags and (op.startswith("global_load_lds") or (op == "s_waitcnt" and ln.strip() == "s_waitcnt vmcnt(4)")):
+            continue
+        out.append(ln)
+    return out
+
+
 def main():
     g = Loop()
     lines = g.build()
+    flags = [f for f in os.environ.get("PBS_ASM_EXP", "").split(",") if f]
+    if flags:
+        lines = experiment_filter(lines, flags)
     v, s = clobbers(lines)
     inputs_v = set([V_ROTWR, V_ROTBASE, V_T] + V_TRWR + V_TRRD + [V_KBASE, V_TW, V_LANE16]) | set(range(V_ACC, V_ACC + 32))
     inputs_s = set([S_KP, S_KP + 1, S_STEPS, S_ACUR, S_A, S_M0ROW])
