@@ -2,7 +2,7 @@
 """CPU execution of the generated blind-rotation loop (tools/pbs_asm/gen.py) against the exact-integer oracle.
 
 Interprets the emitted gfx950 instruction text for one workgroup (8 waves x 64 lanes in lock step, numpy over lanes),
-with the LDS, the key ring's LDS-DMA and the barrier modelled functionally (no latencies: waits are not checked).
+with the LDS, the key ring's LDS-DMA and the barrier modelled functionally (strict about waits: reads and DMA rows take effect only at the s_waitcnt that guarantees them).
 TEST INFRASTRUCTURE: run by hand / by tests while the loop is being changed; nothing in the product imports it.
 
 usage: emu.py [steps]   -> compares the accumulators of 8 bootstraps after `steps` external products with
@@ -33,6 +33,11 @@ class Machine:
         self.lds = np.zeros(G.K_LDS_BYTES + 64, np.uint8)
         self.key = key_bytes          # global memory image of the Fourier key; addresses are offsets into it
         self.count = {}
+        # strict timing model: an LDS read delivers its registers, and an LDS-DMA row lands in the LDS, only at the
+        # s_waitcnt that guarantees it (the latest moment the hardware allows); touching a register whose read is
+        # still in flight is an error
+        self.lds_queue = []           # per LDS operation in flight: None (a write) or (first register, words [k][W][L])
+        self.dma_queue = []           # (destination byte indices, data)
 
     # ---- operand access ----
     def dget(self, r):
@@ -104,8 +109,36 @@ class Machine:
             op, _, rest = ln.partition(" ")
             self.count[op] = self.count.get(op, 0) + 1
             a = [x.strip() for x in rest.split(",")] if rest else []
-            if op in ("s_waitcnt", "s_barrier", "s_nop"):
+            if op == "s_waitcnt":
+                m = re.search(r"lgkmcnt\((\d+)\)", rest)
+                if m:
+                    keep = int(m.group(1))
+                    done, self.lds_queue = self.lds_queue[:len(self.lds_queue) - keep], self.lds_queue[len(self.lds_queue) - keep:] if keep else []
+                    for item in done:
+                        if item is not None:
+                            for k, words in enumerate(item[1]):
+                                self.v[item[0] + k] = words
+                m = re.search(r"vmcnt\((\d+)\)", rest)
+                if m:
+                    keep = int(m.group(1))
+                    done, self.dma_queue = self.dma_queue[:len(self.dma_queue) - keep], self.dma_queue[len(self.dma_queue) - keep:] if keep else []
+                    for dst, data in done:
+                        self.lds[dst] = data
                 continue
+            if op == "s_barrier":
+                assert not any(item is not None and item[2] for item in self.lds_queue), "key reads in flight at a barrier: " + str(pc)
+                continue
+            if op == "s_nop":
+                continue
+            busy = set()
+            for item in self.lds_queue:
+                if item is not None:
+                    busy.update(range(item[0], item[0] + len(item[1])))
+            if busy:
+                used = {r for (kind, r) in G.regs_of(rest) if kind == "v"}
+                if op.startswith("ds_read"):     # a younger read may overwrite an older one's destination: the LDS returns in order
+                    used = {r for (kind, r) in G.regs_of(a[1]) if kind == "v"}
+                assert not (busy & used), "line %d touches v%s while its LDS read is in flight: %s" % (pc, sorted(busy & used), ln)
             if op == "s_mov_b32":
                 self.sdst(a[0], self.ssrc(a[1]))
             elif op == "v_mov_b32":
@@ -172,15 +205,15 @@ class Machine:
                 addr = self.src32(addr_tok) + np.uint32(off)
                 if op == "ds_read_u16":
                     b = self.lds_read(addr, 2)
-                    self.v[int(dst[1:])] = b[..., 0].astype(np.uint32) | (b[..., 1].astype(np.uint32) << 8)
+                    self.lds_queue.append((int(dst[1:]), [b[..., 0].astype(np.uint32) | (b[..., 1].astype(np.uint32) << 8)], False))
                 else:
                     n = 4 if op == "ds_read_b32" else 16
                     assert (addr % n == 0).all(), "misaligned LDS read"
                     b = self.lds_read(addr, n).reshape(W, L, n // 4, 4).astype(np.uint32)
                     words = b[..., 0] | (b[..., 1] << 8) | (b[..., 2] << 16) | (b[..., 3] << 24)
                     r0 = int(re.match(r"v\[?(\d+)", dst).group(1))
-                    for k in range(n // 4):
-                        self.v[r0 + k] = words[..., k]
+                    self.lds_queue.append((r0, [words[..., k].copy() for k in range(n // 4)], addr_tok == "v%d" % G.V_KADDR))
+                    continue
             elif op in ("ds_write_b32", "ds_write_b64"):
                 addr_tok, data_tok = a[0], a[1].split()[0]
                 off = int(re.search(r"offset:(\d+)", rest).group(1)) if "offset:" in rest else 0
@@ -191,6 +224,7 @@ class Machine:
                 words = np.stack([self.v[r0 + k] for k in range(n // 4)], axis=-1)
                 by = np.stack([(words >> np.uint32(8 * j)) & np.uint32(0xFF) for j in range(4)], axis=-1).astype(np.uint8)
                 self.lds_write(addr, by.reshape(W, L, n))
+                self.lds_queue.append(None)
             elif op == "global_load_lds_dwordx4":
                 voff = self.src32(a[0]).astype(np.int64)
                 m = re.fullmatch(r"s\[(\d+):(\d+)\]", a[1])
@@ -199,7 +233,7 @@ class Machine:
                 src = base[:, None] + voff
                 data = self.key[src[..., None] + np.arange(16)]
                 dst = self.m0.astype(np.int64)[:, None] + np.arange(L) * 16
-                self.lds[dst[..., None] + np.arange(16)] = data
+                self.dma_queue.append((dst[..., None] + np.arange(16), data))
             else:
                 raise NotImplementedError(ln)
 

@@ -57,6 +57,8 @@ V_MAGIC = 30                     # v[30:31] = 1.5 * 2^52
 V_ACC = 32
 R_A, R_B, R_K, R_T = 64, 128, 192, 224
 
+AUTO_WAITS = os.environ.get("PBS_ASM_MANUAL_WAITS", "") == ""   # waits and DPP wait states placed by place_waits()
+
 INLINE = {1.0: "1.0", 0.5: "0.5", 2.0: "2.0", 4.0: "4.0"}
 
 
@@ -407,14 +409,15 @@ class Loop:
             for lv in (0, 1):
                 self.e("ds_read_b128 %s, v%d offset:%d" % (qreg(R_K + 16 * lv + 4 * c), V_KADDR, (kk * 8 + lv * 4 + c) * 1024))
 
-    def mac(self, A, B):
+    def mac(self, A, B, prefetched=False):
         """A[k2] <- sum over polynomials and levels of spectrum x key, for all 16 frequency groups (in key order)"""
         e = self.e
         T = [R_T + 2 * j for j in range(8)]          # pr[0..3], pi[0..3]
         pr, pi = T[0:4], T[4:8]
-        self.acquire(0)
-        self.key_issue(0, 0)
-        self.key_issue(0, 1)
+        if not prefetched:
+            self.acquire(0)
+            self.key_issue(0, 0)
+            self.key_issue(0, 1)
         for pos in range(16):
             k2 = kperm(pos)
             more = pos + 1 < 16
@@ -468,39 +471,79 @@ class Loop:
             e("v_add_f64 %s, %s, %s" % (dreg(oi), dreg(pi[0]), dreg(pi[1])))
 
     # ---- the step ---------------------------------------------------------------------------------------------------------
+    def capture(self, fn, *args):
+        """the lines fn emits, as a list (not appended to the output)"""
+        saved, self.out = self.out, []
+        fn(*args)
+        got, self.out = self.out, saved
+        return got
+
+    @staticmethod
+    def spread(main, side, lo=0, hi=None):
+        """main with the instructions of `side` (kept in order) inserted at even distances inside main[lo:hi]"""
+        hi = len(main) if hi is None else hi
+        if not side:
+            return list(main)
+        out, n, k = list(main[:lo]), hi - lo, 0
+        for i in range(n):
+            out.append(main[lo + i])
+            while k < len(side) and (k + 1) * n <= (i + 1) * len(side):
+                out.append(side[k])
+                k += 1
+        out.extend(side[k:])
+        out.extend(main[hi:])
+        return out
+
+    def exchange_after_ready(self, main, X):
+        """main (the transform that leaves X's elements in their home slots) with the stores of the exchange's first
+        plane placed right after the instruction that completes each element, then the rest of the exchange"""
+        out = list(main)
+        last = {}
+        for i, ln in enumerate(main):
+            if ln.startswith("v_"):
+                for reg in regs_of(ln.split(None, 1)[1].split(",")[0]):
+                    last[reg] = i
+        stores = []
+        for r in range(16):
+            reg = X.slot(X.pos[r])[0]
+            stores.append((last.get(("v", reg), -1), "ds_write_b64 v%d, %s offset:%d" % (V_TRWR[r >> 2], dreg(reg), r * 128)))
+        for at, ln in sorted(stores, key=lambda x: -x[0]):
+            out.insert(at + 1, ln)
+        return out
+
     def step(self):
         e = self.e
         A, B = Arr(R_A), Arr(R_B)
         self.rotate_decompose()
-        # forward transform of the level-1 digits; its exchange travels behind the first half of the level-2 transform
+        # level 1: first pass, twiddles, then its exchange travels inside the first pass of level 2
         self.tw_issue(0, 8, R_K)
         self.dft16(A, 1, True)
         self.tw_issue(8, 8, R_T)
-        self.lds_wait(8)
         self.tw_mul(A, 0, 8, R_K, 1)
-        self.lds_wait(0)
         self.tw_mul(A, 8, 8, R_T, 1)
-        self.exchange(A)
-        self.tw_issue(0, 8, R_K)
-        self.dft16(B, 1, True)
+        side = self.capture(self.exchange, A) + self.capture(self.tw_issue, 0, 8, R_K)
+        main = self.capture(self.dft16, B, 1, True)
+        self.out.extend(self.spread(main, side))
         self.tw_issue(8, 8, R_T)
-        self.lds_wait(8)               # A's exchange and the first eight twiddles are in
         self.tw_mul(B, 0, 8, R_K, 1)
-        self.lds_wait(0)
         self.tw_mul(B, 8, 8, R_T, 1)
-        self.exchange(B)
-        self.dft16(A, 1, False)        # cover for B's exchange
-        self.lds_wait(0)
+        # level 2's exchange, the first chunk's barrier and the first key words travel inside the second pass of level 1
+        side = self.capture(self.exchange, B) + self.capture(self.acquire, 0) + self.capture(self.key_issue, 0, 0) + self.capture(self.key_issue, 0, 1)
+        main = self.capture(self.dft16, A, 1, False)
+        self.out.extend(self.spread(main, side))
         self.dft16(B, 1, False)
         # spectrum x key
-        self.mac(A, B)
+        self.mac(A, B, prefetched=True)
         # inverse transform of the sums (array A); array B is free and holds all sixteen twiddles
         e("v_mov_b32 v%d, s%d" % (V_SCR[0], S_ACUR))
         e("ds_read_u16 v%d, v%d" % (V_AREAD, V_SCR[0]))
         self.tw_issue(0, 16, R_B)
-        self.dft16(A, -1, False)
-        self.exchange(A)
-        self.lds_wait(0)
+        main = self.capture(self.dft16, A, -1, False)
+        self.out.extend(self.exchange_after_ready(main, A))
+        for r in range(8):
+            e("ds_read_b128 %s, v%d offset:%d" % (qreg(A.base + 4 * r), V_TRRD[r & 3], 64 * (r >> 2)))
+        self.exchange_plane(A, 1)
+        A.pos = list(range(16))
         e("v_readfirstlane_b32 s%d, v%d" % (S_A, V_AREAD))
         self.tw_mul(A, 0, 16, R_B, -1)
         self.dft16(A, -1, False)
@@ -541,7 +584,7 @@ class Loop:
         e("v_mov_b32 v%d, 0x%x" % (V_MAGIC, mbits & 0xFFFFFFFF))
         e("v_mov_b32 v%d, 0x%x" % (V_MAGIC + 1, mbits >> 32))
         e("L_step%=:")
-        self.out.extend(body.out)
+        self.out.extend(place_waits(body.out) if AUTO_WAITS else body.out)
         e("s_add_u32 s%d, s%d, 0x%x" % (S_KP, S_KP, STEP_KEY_BYTES))
         e("s_addc_u32 s%d, s%d, 0" % (S_KP + 1, S_KP + 1))
         e("s_add_u32 s%d, s%d, 2" % (S_ACUR, S_ACUR))
@@ -550,6 +593,71 @@ class Loop:
         e("s_cbranch_scc1 L_step%=")
         e("s_waitcnt vmcnt(0) lgkmcnt(0)")
         return self.out
+
+
+_REG = __import__("re").compile(r"\b([vs])(?:\[(\d+):(\d+)\]|(\d+))")
+
+
+def regs_of(text):
+    """every VGPR / SGPR named in an operand string, as ("v", n) / ("s", n)"""
+    out = set()
+    for m in _REG.finditer(text):
+        if m.group(2) is not None:
+            out.update((m.group(1), r) for r in range(int(m.group(2)), int(m.group(3)) + 1))
+        else:
+            out.add((m.group(1), int(m.group(4))))
+    return out
+
+
+def lds_dst(ln):
+    """destination registers of an LDS read (empty for everything else)"""
+    if not ln.startswith("ds_read"):
+        return set()
+    return regs_of(ln.split(None, 1)[1].split(",")[0])
+
+
+def place_waits(lines):
+    """Drops the hand-placed LDS waits and DPP wait states and puts back exactly what the final instruction order needs.
+    The LDS returns a wave's operations in issue order, so an instruction that touches the destination of a read still
+    in flight waits until at most N younger operations are outstanding (N capped at 15, the counter's width); a
+    barrier of the key ring waits for every key read issued before it (the chunk they came from is refilled after
+    the barrier).  A DPP move needs two wait states after the vector instruction that wrote its source."""
+    body = [ln for ln in lines if not (ln.startswith("s_waitcnt lgkmcnt(") or ln == "s_nop 1")]
+    out, queue, recent = [], [], []          # queue: [dst regs, is key read] of LDS operations in flight, oldest first
+    for ln in body:
+        if ln.endswith(":"):
+            assert not any(q[0] for q in queue), "LDS reads in flight across a label"
+            out.append(ln)
+            continue
+        op = ln.split()[0]
+        touched = regs_of(ln.split(None, 1)[1]) if " " in ln else set()
+        need = -1
+        for k, (dst, is_key) in enumerate(queue):
+            if (dst & touched) or (is_key and op == "s_barrier"):
+                need = k
+        if op == "s_cbranch_scc1" or "vmcnt(0) lgkmcnt(0)" in ln:
+            need = max([k for k, q in enumerate(queue) if q[0]], default=-1)
+        if need >= 0:
+            n = min(len(queue) - 1 - need, 15)
+            out.append("s_waitcnt lgkmcnt(%d)" % n)
+            queue = queue[len(queue) - n:] if n else []
+        if "_dpp" in op:
+            src = regs_of(ln.split(None, 1)[1].split(",")[1].split()[0])
+            for back, w in enumerate(reversed(recent[-2:])):
+                if w & src:
+                    out.append("s_nop %d" % (1 - back))
+                    recent.append(set())
+                    if back == 0:
+                        recent.append(set())
+                    break
+        out.append(ln)
+        if op.startswith("ds_"):
+            queue.append((lds_dst(ln), op == "ds_read_b128" and ", v%d " % V_KADDR in ln + " "))
+        if op.startswith("v_"):
+            recent.append(regs_of(ln.split(None, 1)[1].split(",")[0]))
+        elif not op.startswith("s_waitcnt"):
+            recent.append(set())
+    return out
 
 
 def clobbers(lines):
