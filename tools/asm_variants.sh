@@ -1,0 +1,13 @@
+#!/bin/bash
+# Builds one experiment library per schedule variant of the hand-scheduled loop: tools/asm_variants.sh name=opt1,opt2 ...
+# (PBS_ASM_OPT flags of tools/pbs_asm/gen.py; "name=" alone is the default schedule), checks each on the CPU emulator first.
+set -e
+cd "$(dirname "$0")/.."
+mkdir -p tools/exp
+for v in "$@"; do
+  n=${v%%=*}; f=${v#*=}
+  PBS_ASM_OPT=$f python3 tools/pbs_asm/gen.py tools/exp/loop_$n.inc > /dev/null
+  (PBS_ASM_OPT=$f python3 tools/pbs_asm/emu.py 1 | grep -q "mismatching words 0" || { echo "variant $n fails on the emulator"; exit 1; }
+   tools/build_exp.sh asm_$n "-DTFA_PBS_ASM_INC=\"../../tools/exp/loop_$n.inc\"" 2>&1 | grep -iE "error" || true) &
+done
+wait

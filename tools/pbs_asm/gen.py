@@ -25,7 +25,8 @@ K_TR_GROUP = 260
 K_WAVE_LDS = 8320
 K_WAVE_BYTES = 8320 + 1664
 K_TW_OFFSET = 8 * K_WAVE_BYTES
-K_RING_OFFSET = K_TW_OFFSET + 4096
+K_TW_ROW_BYTES = 256       # twiddle table [element][t], 16 bytes each
+K_RING_OFFSET = K_TW_OFFSET + 16 * K_TW_ROW_BYTES
 K_CHUNK_BYTES = 16384
 K_LDS_BYTES = K_RING_OFFSET + 4 * K_CHUNK_BYTES
 STEP_KEY_BYTES = 131072
@@ -57,6 +58,8 @@ V_MAGIC = 30                     # v[30:31] = 1.5 * 2^52
 V_ACC = 32
 R_A, R_B, R_K, R_T = 64, 128, 192, 224
 
+# schedule choices that can be switched off for measurement (PBS_ASM_OPT=comma list replaces the default set)
+OPT = set(f for f in os.environ.get("PBS_ASM_OPT", "mac_il,tw_spread,inv_split").split(",") if f)
 AUTO_WAITS = os.environ.get("PBS_ASM_MANUAL_WAITS", "") == ""   # waits and DPP wait states placed by place_waits()
 
 INLINE = {1.0: "1.0", 0.5: "0.5", 2.0: "2.0", 4.0: "4.0"}
@@ -350,7 +353,7 @@ class Loop:
     # ---- twiddles -------------------------------------------------------------------------------------------------------
     def tw_issue(self, k0, count, region):
         for k in range(count):
-            self.e("ds_read_b128 %s, v%d offset:%d" % (qreg(region + 4 * k), V_TW, (k0 + k) * 256))
+            self.e("ds_read_b128 %s, v%d offset:%d" % (qreg(region + 4 * k), V_TW, (k0 + k) * K_TW_ROW_BYTES))
 
     def tw_mul(self, X, k0, count, region, S):
         """X[k0 .. k0+count) *= (c + i S s) in place, entry j of `region` = (c, s) of element k0 + j"""
@@ -363,6 +366,23 @@ class Loop:
             e("v_mul_f64 %s, %s, %s" % (dreg(m2.reg), z.r.s(), s.s()))
             e("v_fma_f64 %s, %s, %s, %s" % (dreg(z.r.reg), z.r.s(), c.s(), m1.s(flip=S > 0)))
             e("v_fma_f64 %s, %s, %s, %s" % (dreg(z.i.reg), z.i.s(), c.s(), m2.s(flip=S < 0)))
+
+    def tw_mul_first(self, X, count, region, scratch):
+        """Phase 1 of X[k] *= (c - i s) (the inverse transform's twiddles), from the real parts alone:
+        scratch[k] = re s, re <- re c"""
+        for j in range(count):
+            c, s_ = V(region + 4 * j), V(region + 4 * j + 2)
+            z = X.val(j)
+            self.e("v_mul_f64 %s, %s, %s" % (dreg(scratch + 2 * j), z.r.s(), s_.s()))
+            self.e("v_mul_f64 %s, %s, %s" % (dreg(z.r.reg), z.r.s(), c.s()))
+
+    def tw_mul_second(self, X, count, region, scratch):
+        """Phase 2, once the imaginary parts have arrived: re <- re c + im s, im <- im c - re s"""
+        for j in range(count):
+            c, s_ = V(region + 4 * j), V(region + 4 * j + 2)
+            z = X.val(j)
+            self.e("v_fma_f64 %s, %s, %s, %s" % (dreg(z.r.reg), z.i.s(), s_.s(), z.r.s()))
+            self.e("v_fma_f64 %s, %s, %s, -%s" % (dreg(z.i.reg), z.i.s(), c.s(), dreg(scratch + 2 * j)))
 
     # ---- exchange -------------------------------------------------------------------------------------------------------
     def exchange_plane(self, X, plane):
@@ -424,11 +444,9 @@ class Loop:
             opens = more and (pos + 1) % 2 == 0
             f1, f2 = A.val(k2), B.val(k2)
             if opens:
-                self.lds_wait(0)          # the whole chunk is in registers before the barrier that lets it be refilled
-                self.acquire((pos + 1) // 2)
+                self.acquire((pos + 1) // 2)   # place_waits() drains the old chunk's reads before the barrier
+            prod = []
             for pair in (0, 1):
-                if not opens:
-                    self.lds_wait(4 if (pair == 0 or more) else 0)
                 cols = (2 * pair, 2 * pair + 1)
                 b0 = {c: (V(R_K + 4 * c), V(R_K + 4 * c + 2)) for c in cols}
                 b1 = {c: (V(R_K + 16 + 4 * c), V(R_K + 16 + 4 * c + 2)) for c in cols}
@@ -444,31 +462,36 @@ class Loop:
                                       "v_fma_f64 %s, %s, %s, %s" % (dreg(pi[c]), f1.i.s(), x0.s(), dreg(pi[c])),
                                       "v_fma_f64 %s, %s, %s, %s" % (dreg(pi[c]), f2.r.s(), y1.s(), dreg(pi[c])),
                                       "v_fma_f64 %s, %s, %s, %s" % (dreg(pi[c]), f2.i.s(), x1.s(), dreg(pi[c]))]
-                for step in range(4):
-                    for ch in range(4):
-                        e(seq[ch][step])
-                if more:
-                    self.key_issue(pos + 1, pair)
+                prod.append([seq[ch][step] for step in range(4) for ch in range(4)])
             # sum over the four polynomials of the quad, scattered so that lane g ends with output polynomial g:
             # lane g's p[j] belongs to output j ^ g.  Two values from the neighbour at distance 2, one at distance 1.
+            red = []
             def dpp(reg, ctrl):
                 for h in (0, 1):
-                    e("v_mov_b32_dpp v%d, v%d quad_perm:%s row_mask:0xf bank_mask:0xf" % (reg + h, reg + h, ctrl))
+                    red.append("v_mov_b32_dpp v%d, v%d quad_perm:%s row_mask:0xf bank_mask:0xf" % (reg + h, reg + h, ctrl))
             X2, X1 = "[2,3,0,1]", "[1,0,3,2]"
             dpp(pr[2], X2)
             dpp(pi[2], X2)
             dpp(pr[3], X2)
             dpp(pi[3], X2)
-            e("v_add_f64 %s, %s, %s" % (dreg(pr[0]), dreg(pr[0]), dreg(pr[2])))     # sa (real)
-            e("v_add_f64 %s, %s, %s" % (dreg(pr[1]), dreg(pr[1]), dreg(pr[3])))     # sb (real)
-            e("v_add_f64 %s, %s, %s" % (dreg(pi[0]), dreg(pi[0]), dreg(pi[2])))
-            e("v_add_f64 %s, %s, %s" % (dreg(pi[1]), dreg(pi[1]), dreg(pi[3])))
-            e("s_nop 1")
+            red.append("v_add_f64 %s, %s, %s" % (dreg(pr[0]), dreg(pr[0]), dreg(pr[2])))     # sa (real)
+            red.append("v_add_f64 %s, %s, %s" % (dreg(pr[1]), dreg(pr[1]), dreg(pr[3])))     # sb (real)
+            red.append("v_add_f64 %s, %s, %s" % (dreg(pi[0]), dreg(pi[0]), dreg(pi[2])))
+            red.append("v_add_f64 %s, %s, %s" % (dreg(pi[1]), dreg(pi[1]), dreg(pi[3])))
             dpp(pr[1], X1)
             dpp(pi[1], X1)
             orr, oi = A.slot(A.pos[k2])
-            e("v_add_f64 %s, %s, %s" % (dreg(orr), dreg(pr[0]), dreg(pr[1])))
-            e("v_add_f64 %s, %s, %s" % (dreg(oi), dreg(pi[0]), dreg(pi[1])))
+            red.append("v_add_f64 %s, %s, %s" % (dreg(orr), dreg(pr[0]), dreg(pr[1])))
+            red.append("v_add_f64 %s, %s, %s" % (dreg(oi), dreg(pi[0]), dreg(pi[1])))
+            # the next position's key words: a pair's registers are refilled while the other pair multiplies / the sums travel
+            nxt0 = self.capture(self.key_issue, pos + 1, 0) if more else []
+            nxt1 = self.capture(self.key_issue, pos + 1, 1) if more else []
+            if "mac_il" in OPT:
+                self.out.extend(prod[0])
+                self.out.extend(self.spread(prod[1], nxt0))
+                self.out.extend(self.spread(red, nxt1))
+            else:
+                self.out.extend(prod[0] + nxt0 + prod[1] + nxt1 + red)
 
     # ---- the step ---------------------------------------------------------------------------------------------------------
     def capture(self, fn, *args):
@@ -518,14 +541,12 @@ class Loop:
         # level 1: first pass, twiddles, then its exchange travels inside the first pass of level 2
         self.tw_issue(0, 8, R_K)
         self.dft16(A, 1, True)
-        self.tw_issue(8, 8, R_T)
-        self.tw_mul(A, 0, 8, R_K, 1)
+        self.out.extend(self.spread(self.capture(self.tw_mul, A, 0, 8, R_K, 1), self.capture(self.tw_issue, 8, 8, R_T), 0, 32 if "tw_spread" in OPT else 0))
         self.tw_mul(A, 8, 8, R_T, 1)
         side = self.capture(self.exchange, A) + self.capture(self.tw_issue, 0, 8, R_K)
         main = self.capture(self.dft16, B, 1, True)
         self.out.extend(self.spread(main, side))
-        self.tw_issue(8, 8, R_T)
-        self.tw_mul(B, 0, 8, R_K, 1)
+        self.out.extend(self.spread(self.capture(self.tw_mul, B, 0, 8, R_K, 1), self.capture(self.tw_issue, 8, 8, R_T), 0, 32 if "tw_spread" in OPT else 0))
         self.tw_mul(B, 8, 8, R_T, 1)
         # level 2's exchange, the first chunk's barrier and the first key words travel inside the second pass of level 1
         side = self.capture(self.exchange, B) + self.capture(self.acquire, 0) + self.capture(self.key_issue, 0, 0) + self.capture(self.key_issue, 0, 1)
@@ -537,15 +558,20 @@ class Loop:
         # inverse transform of the sums (array A); array B is free and holds all sixteen twiddles
         e("v_mov_b32 v%d, s%d" % (V_SCR[0], S_ACUR))
         e("ds_read_u16 v%d, v%d" % (V_AREAD, V_SCR[0]))
-        self.tw_issue(0, 16, R_B)
         main = self.capture(self.dft16, A, -1, False)
+        main = self.spread(main, self.capture(self.tw_issue, 0, 16, R_B), 0, 64 if "tw_spread" in OPT else 0)
         self.out.extend(self.exchange_after_ready(main, A))
         for r in range(8):
             e("ds_read_b128 %s, v%d offset:%d" % (qreg(A.base + 4 * r), V_TRRD[r & 3], 64 * (r >> 2)))
         self.exchange_plane(A, 1)
         A.pos = list(range(16))
         e("v_readfirstlane_b32 s%d, v%d" % (S_A, V_AREAD))
-        self.tw_mul(A, 0, 16, R_B, -1)
+        # the twiddle products that need only the real parts run while the imaginary plane is on its way
+        if "inv_split" in OPT:
+            self.tw_mul_first(A, 16, R_B, R_K)
+            self.tw_mul_second(A, 16, R_B, R_K)
+        else:
+            self.tw_mul(A, 0, 16, R_B, -1)
         self.dft16(A, -1, False)
         # untwist by e^{-i pi n1 / 32}, round to the torus, accumulate, and put the new accumulator into the rotation buffer
         st = Stream(self, self.pool)
@@ -687,6 +713,10 @@ def experiment_filter(lines, flags):
             continue
         if "notw" in flags and op == "ds_read_b128" and ", v%d " % V_TW in ln:
             continue
+        if "twlane" in flags and op == "ds_read_b128" and ", v%d " % V_TW in ln:
+            ln = ln.replace(", v%d " % V_TW, ", v%d " % V_LANE16)     # one distinct 16-byte word per lane instead of one per four lanes
+            k = int(ln.split("offset:")[1])
+            ln = ln.split("offset:")[0] + "offset:%d" % ((k // K_TW_ROW_BYTES) * 1024)
         if "noexch" in flags and (op == "ds_write_b64" or (op == "ds_read_b128" and any(", v%d " % r in ln for r in V_TRRD))):
             continue
         if "norot" in flags and op in ("ds_read_b32", "ds_write_b32"):
