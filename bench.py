@@ -52,7 +52,7 @@ def measured_traffic():
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 cur = json.load(f)["counters_current_kernels"]
-            c = next(v for k, v in cur.items() if k.startswith("tfa::pbs_kernel<8"))
+            c = next(v for k, v in cur.items() if "pbs_asm_kernel<0>" in k or k.startswith("tfa::pbs_kernel<8"))
             return int((2 * c["FETCH_SIZE@65536"] + c["WRITE_SIZE@65536"]) * 1024), name
         except (OSError, KeyError, ValueError, StopIteration):
             continue
@@ -417,7 +417,7 @@ def main():
             "wrong_results": wrong,
             # the contract's two bounds are hbm and mfma; this kernel is bound by the fp64 arithmetic peak, which on
             # MI355X is the same number for the vector units it runs on and for the matrix cores ("bound_detail")
-            "roofline": {"bound": "mfma", "bound_detail": "fp64 vector FMA units (peak equal to the fp64 matrix peak)", "kernel": "pbs_kernel",
+            "roofline": {"bound": "mfma", "bound_detail": "fp64 vector FMA units (peak equal to the fp64 matrix peak)", "kernel": "pbs_asm_kernel",
                          "achieved": round(achieved, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP64_PEAK_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": f"HBM bytes per launch (rocprofv3 PMC passes, profiles/{traffic_src})",

@@ -64,6 +64,10 @@ struct tfa_ctx {
     bool ks_valu = false;  // TFA_KS_VALU=1: keep the keyswitch on the vector ALUs (the generic-parameter path; for comparison)
     bool trace = false;   // TFA_TRACE=1: one stderr line per submitted stage
     bool pbs_asm = true;  // TFA_PBS_ASM=0: the 8-wave mapping runs the compiler-scheduled kernel instead of the hand-scheduled loop
+    // time of one round of workgroups over all CUs per mapping, microseconds: [0] 8 bootstraps per workgroup, [1] 4 per
+    // workgroup, [2] one bootstrap per workgroup and one workgroup per CU, [3] the same with two workgroups per CU.
+    // Measured on this device after the key upload (calibrate_rounds); the defaults are an MI355X at 2.4 GHz.
+    double round_us[4] = {10000, 7600, 3000, 5100};
     int force_waves = 0;  // 0 = choose per launch; 1 / 2 (latency kernel, workgroups per CU), 4 or 8 pins the kernel variant (TFA_PBS_WAVES, for experiments)
     std::vector<EventPair> pending;
     // per-stage validation marks, sized with the pool: slot_mark[s] = stamp of the stage that last wrote s,
@@ -90,6 +94,7 @@ static int fail(tfa_ctx *ctx, int code, const std::string &msg) {
     return code;
 }
 static int noalloc_setup(tfa_ctx *ctx);
+static int calibrate_rounds(tfa_ctx *ctx);
 
 static int ensure_io(tfa_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->io_cap) return TFA_OK;
@@ -231,7 +236,8 @@ extern "C" int tfa_ctx_create(const tfa_params *p, int hip_device, tfa_ctx **out
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bsk_convert_lat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLatConvertLdsBytes));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, PbsGeom<4>::kLdsBytes));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, PbsGeom<8>::kLdsBytes));
-    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_asm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PbsGeom<8>::kLdsBytes));
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_asm_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, PbsGeom<8>::kLdsBytes));
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_asm_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, PbsGeom<8>::kLdsBytes));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bsk_convert_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kConvertLdsBytes));
     return noalloc_setup(ctx);
 }
@@ -312,7 +318,7 @@ extern "C" int tfa_keys_upload(tfa_ctx *ctx, const uint32_t *bsk, const uint32_t
     hipFree(d_std);
     if (e != hipSuccess) return fail(ctx, TFA_EHIP, std::string("bsk upload/convert: ") + hipGetErrorString(e));
     ctx->have_keys = true;
-    return TFA_OK;
+    return calibrate_rounds(ctx);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -423,6 +429,92 @@ extern "C" int tfa_pool_device_ptr(tfa_ctx *ctx, void **dptr, uint32_t *stride_w
 }
 
 // ---------------------------------------------------------------------------------------------
+// One launch of a bootstrap mapping: 8 / 4 = bootstraps per workgroup (one wave each), 1 / 2 = one bootstrap spread over a
+// workgroup's four waves with that many workgroups per CU.
+static void launch_variant(tfa_ctx *ctx, int variant, const uint32_t *in_base, uint32_t in_stride, const PbsJob *jobs, uint32_t count, uint32_t steps,
+                           uint32_t *big, uint32_t *acc, bool calibration = false) {
+    if (variant == 8 && ctx->pbs_asm && calibration)
+        hipLaunchKernelGGL(pbs_asm_kernel<1>, dim3((count + 7) / 8), dim3(512), PbsGeom<8>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
+                           ctx->d_bsk_f, ctx->d_tw, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
+    else if (variant == 8 && ctx->pbs_asm)
+        hipLaunchKernelGGL(pbs_asm_kernel<0>, dim3((count + 7) / 8), dim3(512), PbsGeom<8>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
+                           ctx->d_bsk_f, ctx->d_tw, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
+    else if (variant == 8)
+        hipLaunchKernelGGL(pbs_kernel<8>, dim3((count + 7) / 8), dim3(512), PbsGeom<8>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
+                           ctx->d_bsk_f, ctx->d_tw, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
+    else if (variant == 4)
+        hipLaunchKernelGGL(pbs_kernel<4>, dim3((count + 3) / 4), dim3(256), PbsGeom<4>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
+                           ctx->d_bsk_f, ctx->d_tw, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
+    else if (variant == 2)
+        hipLaunchKernelGGL(pbs_lat_kernel<2>, dim3(count), dim3(256), LatGeom<2>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
+                           ctx->d_bsk_lat, ctx->d_tw_lat, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
+    else
+        hipLaunchKernelGGL(pbs_lat_kernel<1>, dim3(count), dim3(256), LatGeom<1>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
+                           ctx->d_bsk_lat, ctx->d_tw_lat, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
+}
+
+// Round times of the four mappings on this device: each mapping runs one full round of workgroups for two step counts,
+// and the line through the two timings gives the time of a complete blind rotation (slope) plus the launch's fixed part.
+// Results are kept per device for the life of the process; TFA_NO_CALIBRATE=1 keeps the built-in table.
+namespace {
+struct RoundTable {
+    bool valid = false;
+    double us[4];
+};
+RoundTable g_round_table[64];
+}  // namespace
+
+static int calibrate_rounds(tfa_ctx *ctx) {
+    if (getenv("TFA_NO_CALIBRATE") || ctx->device >= 64) return TFA_OK;
+    RoundTable &tab = g_round_table[ctx->device];
+    if (!tab.valid) {
+        const uint32_t cus = ctx->n_cus, max_jobs = 8 * cus, n = ctx->p.lwe_dimension;
+        uint32_t *d_in = nullptr, *d_big = nullptr;
+        PbsJob *d_jobs = nullptr;
+        HIPCHK(ctx, hipMalloc(&d_in, 2 * (size_t)ctx->pool_stride * sizeof(uint32_t)));
+        hipError_t e = hipMalloc(&d_big, (size_t)max_jobs * ctx->big_stride * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(&d_jobs, max_jobs * sizeof(PbsJob));
+        std::vector<PbsJob> jobs(max_jobs, PbsJob{0, 1, 1, 1, 1u << 29, {0, 0, 0}});
+        std::vector<uint32_t> in(2 * (size_t)ctx->pool_stride);
+        for (size_t i = 0; i < in.size(); i++) in[i] = (uint32_t)(i * 2654435761u);  // any mask: the time does not depend on the data
+        if (e == hipSuccess) e = hipMemcpy(d_in, in.data(), in.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_jobs, jobs.data(), jobs.size() * sizeof(PbsJob), hipMemcpyHostToDevice);
+        hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+        for (auto &x : ev)
+            if (e == hipSuccess) e = hipEventCreate(&x);
+        const int variants[4] = {8, 4, 1, 2};
+        const uint32_t widths[4] = {8 * cus, 4 * cus, cus, 2 * cus}, s0 = 100, s1 = 300;
+        // the shader clock takes a few milliseconds of load to come up from idle: one complete round first
+        if (e == hipSuccess) launch_variant(ctx, 8, d_in, ctx->pool_stride, d_jobs, widths[0], n, d_big, nullptr, true);
+        for (int v = 0; v < 4 && e == hipSuccess; v++) {
+            launch_variant(ctx, variants[v], d_in, ctx->pool_stride, d_jobs, widths[v], s0, d_big, nullptr, true);  // warm-up: code and key in the caches
+            hipEventRecord(ev[0], ctx->stream);
+            launch_variant(ctx, variants[v], d_in, ctx->pool_stride, d_jobs, widths[v], s0, d_big, nullptr, true);
+            hipEventRecord(ev[1], ctx->stream);
+            launch_variant(ctx, variants[v], d_in, ctx->pool_stride, d_jobs, widths[v], s1, d_big, nullptr, true);
+            hipEventRecord(ev[2], ctx->stream);
+            e = hipEventSynchronize(ev[2]);
+            if (e == hipSuccess) e = hipGetLastError();
+            float ms0 = 0, ms1 = 0;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms0, ev[0], ev[1]);
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms1, ev[1], ev[2]);
+            const double per_step = (ms1 - ms0) / (double)(s1 - s0), fixed = ms0 - per_step * s0;
+            tab.us[v] = 1000.0 * (per_step * n + (fixed > 0 ? fixed : 0));
+            if (!(per_step > 0)) e = hipErrorUnknown;
+        }
+        for (auto &x : ev)
+            if (x) hipEventDestroy(x);
+        hipFree(d_in);
+        hipFree(d_big);
+        hipFree(d_jobs);
+        if (e != hipSuccess) return fail(ctx, TFA_EHIP, std::string("round-time calibration: ") + hipGetErrorString(e));
+        tab.valid = true;
+    }
+    for (int v = 0; v < 4; v++) ctx->round_us[v] = tab.us[v];
+    if (ctx->trace) fprintf(stderr, "tfa round times (us): 8/wg %.0f, 4/wg %.0f, 1 wg/CU %.0f, 2 wg/CU %.0f\n", tab.us[0], tab.us[1], tab.us[2], tab.us[3]);
+    return TFA_OK;
+}
+
 static int launch_pbs(tfa_ctx *ctx, const uint32_t *in_base, uint32_t in_stride, const PbsJob *d_jobs, uint32_t n_jobs, uint32_t steps,
                       uint32_t *acc_out, uint32_t *big_base, bool timed = true) {
     if (n_jobs == 0) return TFA_OK;
@@ -433,46 +525,27 @@ static int launch_pbs(tfa_ctx *ctx, const uint32_t *in_base, uint32_t in_stride,
         HIPCHK(ctx, hipEventCreate(&ep.b));
         HIPCHK(ctx, hipEventRecord(ep.a, ctx->stream));
     }
-    // Four mappings, picked by which finishes soonest on the device's CUs (measured time of one round of
-    // workgroups over all CUs, microseconds, MI355X):
-    //   8 bootstraps per workgroup, two waves per SIMD (highest throughput)          11000 per 8 * CUs
-    //   4 bootstraps per workgroup, one wave per SIMD                                  7600 per 4 * CUs
-    //   one bootstrap spread over the 4 waves of a workgroup, one workgroup per CU    3000 per CUs
-    //   the same with two workgroups per CU                                           5100 per 2 * CUs
-    // A batch that fills whole rounds of the 8-wave kernel and leaves a short tail runs the tail separately.
+    // Four mappings, picked by which finishes soonest on the device's CUs, from the round times in ctx->round_us.
+    // A batch that fills whole rounds of the 8-per-workgroup kernel and leaves a short tail runs the tail separately.
     const uint64_t cus = ctx->n_cus;
-    auto best_single = [&](uint64_t P, int &variant) -> uint64_t {
-        const uint64_t t8 = ((P + 8 * cus - 1) / (8 * cus)) * 11000, t4 = ((P + 4 * cus - 1) / (4 * cus)) * 7600;
-        const uint64_t lat_rest = P % (2 * cus), t_lat = (P / (2 * cus)) * 5100 + (lat_rest == 0 ? 0 : lat_rest <= cus ? 3000 : 5100);
+    const double r8 = ctx->round_us[0], r4 = ctx->round_us[1], rl1 = ctx->round_us[2], rl2 = ctx->round_us[3];
+    auto best_single = [&](uint64_t P, int &variant) -> double {
+        const double t8 = (double)((P + 8 * cus - 1) / (8 * cus)) * r8, t4 = (double)((P + 4 * cus - 1) / (4 * cus)) * r4;
+        const uint64_t lat_rest = P % (2 * cus);
+        const double t_lat = (double)(P / (2 * cus)) * rl2 + (lat_rest == 0 ? 0.0 : lat_rest <= cus ? rl1 : rl2);
         variant = t_lat <= t4 && t_lat <= t8 ? (P > cus ? 2 : 1) : (t8 < t4 ? 8 : 4);
         return variant == 8 ? t8 : variant == 4 ? t4 : t_lat;
     };
     auto launch = [&](int variant, uint32_t first, uint32_t count) {
-        const PbsJob *jobs = d_jobs + first;
-        uint32_t *big = big_base + (size_t)first * ctx->big_stride;
-        uint32_t *acc = acc_out ? acc_out + (size_t)first * kK1 * kN : nullptr;
-        if (variant == 8 && ctx->pbs_asm)
-            hipLaunchKernelGGL(pbs_asm_kernel, dim3((count + 7) / 8), dim3(512), PbsGeom<8>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
-                               ctx->d_bsk_f, ctx->d_tw, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
-        else if (variant == 8)
-            hipLaunchKernelGGL(pbs_kernel<8>, dim3((count + 7) / 8), dim3(512), PbsGeom<8>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
-                               ctx->d_bsk_f, ctx->d_tw, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
-        else if (variant == 4)
-            hipLaunchKernelGGL(pbs_kernel<4>, dim3((count + 3) / 4), dim3(256), PbsGeom<4>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
-                               ctx->d_bsk_f, ctx->d_tw, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
-        else if (variant == 2)
-            hipLaunchKernelGGL(pbs_lat_kernel<2>, dim3(count), dim3(256), LatGeom<2>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
-                               ctx->d_bsk_lat, ctx->d_tw_lat, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
-        else
-            hipLaunchKernelGGL(pbs_lat_kernel<1>, dim3(count), dim3(256), LatGeom<1>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
-                               ctx->d_bsk_lat, ctx->d_tw_lat, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
+        launch_variant(ctx, variant, in_base, in_stride, d_jobs + first, count, steps, big_base + (size_t)first * ctx->big_stride,
+                       acc_out ? acc_out + (size_t)first * kK1 * kN : nullptr);
     };
     int variant = 0, tail_variant = 0;
-    const uint64_t t_single = best_single(n_jobs, variant);
+    const double t_single = best_single(n_jobs, variant);
     const uint32_t full = (uint32_t)((n_jobs / (8 * cus)) * (8 * cus));
     if (ctx->force_waves) {
         launch(ctx->force_waves, 0, n_jobs);
-    } else if (full > 0 && full < n_jobs && (full / (8 * cus)) * 11000 + best_single(n_jobs - full, tail_variant) < t_single) {
+    } else if (full > 0 && full < n_jobs && (double)(full / (8 * cus)) * r8 + best_single(n_jobs - full, tail_variant) < t_single) {
         launch(8, 0, full);
         HIPCHK(ctx, hipGetLastError());
         launch(tail_variant, full, n_jobs - full);

@@ -3,7 +3,7 @@
 # counter group over tools/prof_pbs.py.  Every pass runs on its own, under its own time limit; the first failure stops.
 # usage: tools/profile_round.sh <tag>   -> gpurun_out/prof_<tag>/...
 set -e
-tag=${1:-r1}
+tag=${1:-r2}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
