@@ -1,6 +1,8 @@
 // Command-line driver with the flags and printed lines of the reference binary
 // (/root/reference/tfhe-aes/src/main.rs:15-32 flags, :127-400 the four mode tests): random blocks are
-// encrypted and decrypted homomorphically on the GPU and compared with a clear AES-128.
+// encrypted and decrypted homomorphically on the GPU and compared with a clear AES-128 (the reference compares with the
+// `aes` crate, main.rs:136-141; here the clear cipher is the one of host/sbox.cpp's tables, which tests/test_aes_clear.py
+// pins to FIPS-197 and SP 800-38A).  Additional lines: key generation time and the engine's gate / stage counts.
 //   tfhe-aes-hip -k <32 hex> -i <32 hex> [-n outputs] [-x] [-m ECB|CBC|CTR|OFB] [--seed S] [--device D]
 // --seed / --device have no counterpart in the reference (its keys come from OS entropy, it has no GPU).
 #include <array>
@@ -79,17 +81,18 @@ static Block add_counter(const Block &iv, uint64_t k) {
 }
 
 static std::vector<Key> key_expansion(const Block &key, bool offline, ServerKey &sk, const ClientKey &ck) {
+    // the two lines of tfhe-aes/src/main.rs:397-415
+    printf("---Key Expansion (%s)---\n", offline ? "offline" : "online");
     std::vector<Key> keys;
     const auto t0 = Clock::now();
     if (offline) {
         for (const auto &k : key_expansion_clear(key)) keys.push_back(Key::from_u8_enc(k, ck));
-        printf("Key expansion (offline) done in: %.3fs\n", seconds_since(t0));
     } else {
         const auto rk = Key::from_u8_enc(key, ck).generate_round_keys(sk);
         sk.flush();
         keys.assign(rk.begin(), rk.end());
-        printf("Key expansion (online, encrypted) done in: %.3fs\n", seconds_since(t0));
     }
+    printf("AES key expansion took: %.3fs\n", seconds_since(t0));
     return keys;
 }
 static std::vector<State> to_states(const std::vector<Block> &blocks, const ClientKey &ck) {
@@ -160,7 +163,11 @@ int main(int argc, char **argv) {
         printf("Key generation and upload: %.3fs\n", seconds_since(t0));
         ServerKey &sk = *kp.server;
         const ClientKey &ck = *kp.client;
-        printf("---Testing %s mode---\n", mode.c_str());
+        // banners as the reference prints them: "---Testing ECB mode---" (main.rs:134), "Testing CBC mode" (:206, :270, :336)
+        if (mode == "ECB")
+            printf("---Testing ECB mode---\n");
+        else
+            printf("Testing %s mode\n", mode.c_str());
         const std::vector<Key> keys = key_expansion(key, offline, sk, ck);
         printf("---Begin Encryption---\n");
         t0 = Clock::now();
@@ -197,7 +204,8 @@ int main(int argc, char **argv) {
         printf("AES of #%d outputs decrypted in: %.3fs\n", n, seconds_since(t0));
         expect_equal(states, blocks, ck, "decryption");
         const ServerKeyStats st = sk.stats();
-        printf("%s mode test passed (%llu gates in %llu stages, widest %llu)\n", mode.c_str(), (unsigned long long)st.gates, (unsigned long long)st.stages,
+        printf("%s mode test passed\n", mode.c_str());
+        printf("engine: %llu gates in %llu stages, widest %llu\n", (unsigned long long)st.gates, (unsigned long long)st.stages,
                (unsigned long long)st.max_stage_width);
     } catch (const std::exception &e) {
         fprintf(stderr, "error: %s\n", e.what());

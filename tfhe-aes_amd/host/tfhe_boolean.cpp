@@ -87,7 +87,7 @@ ServerKey::ServerKey(const tfa_params &p, const uint32_t *bsk, const uint32_t *k
         ctx_ = nullptr;
         throw std::runtime_error("tfa_keys_upload failed: " + msg);
     }
-    pool_slots_ = 1u << 14;
+    pool_slots_ = 1u << 17;  // 131072 slots = 424 MB: one AES block in flight (72 k slots) without a reallocation
     check(ctx_, tfa_pool_reserve(ctx_, pool_slots_), "tfa_pool_reserve");
 }
 
@@ -187,6 +187,7 @@ Ciphertext ServerKey::binary(uint32_t op, const Ciphertext &a, const Ciphertext 
         default: return t ? e : not_(e);
         }
     }
+    auto_flush();
     Resolved in[2] = {resolve(a), resolve(b)};
     return record(op, in, 2);
 }
@@ -201,8 +202,16 @@ Ciphertext ServerKey::mux(const Ciphertext &cond, const Ciphertext &then_ct, con
     if (cond.is_trivial()) return cond.value_ ? then_ct : else_ct;
     if (then_ct.is_trivial()) return then_ct.value_ ? or_(cond, else_ct) : and_(not_(cond), else_ct);
     if (else_ct.is_trivial()) return else_ct.value_ ? or_(then_ct, not_(cond)) : and_(cond, then_ct);
+    auto_flush();
     Resolved in[3] = {resolve(cond), resolve(then_ct), resolve(else_ct)};
     return record(TFA_MUX, in, 3);
+}
+
+// Every recorded gate holds a fresh pool slot until the flush, so an unbounded recording (the command line records up to 255
+// blocks before it reads a result) would size the pool by the job, not by the GPU: past kAutoFlushGates pending gates the
+// recording is run before the next gate is taken.  Results do not change; only gates on either side of the cut stop sharing stages.
+void ServerKey::auto_flush() {
+    if (pending_count_ >= kAutoFlushGates) flush();
 }
 
 void ServerKey::upload_pending() {

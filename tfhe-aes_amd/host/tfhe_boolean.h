@@ -99,6 +99,7 @@ class ServerKey {
     tfa_ctx *context() const { return ctx_; }
     ServerKeyStats stats() const { return stats_; }
     uint64_t pending_gates() const { return pending_count_; }
+    static constexpr uint64_t kAutoFlushGates = 2000000;  // about 28 AES blocks in flight = 6.5 GB of pool
 
   private:
     friend struct detail::SlotRef;
@@ -112,6 +113,7 @@ class ServerKey {
     uint32_t alloc_slot();
     void release_slot(uint32_t slot);
     void upload_pending();
+    void auto_flush();
 
     tfa_params p_;
     tfa_ctx *ctx_ = nullptr;
