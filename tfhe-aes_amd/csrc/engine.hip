@@ -15,6 +15,7 @@
 #include "pbs_kernel.h"
 #include "pbs_asm_kernel.h"
 #include "pbs_lat_kernel.h"
+#include "pbs_lat_asm_kernel.h"
 
 using namespace tfa;
 
@@ -63,6 +64,7 @@ struct tfa_ctx {
     uint32_t n_cus = 256;
     bool ks_valu = false;  // TFA_KS_VALU=1: keep the keyswitch on the vector ALUs (the generic-parameter path; for comparison)
     bool trace = false;   // TFA_TRACE=1: one stderr line per submitted stage
+    bool lat_asm = true;  // TFA_LAT_ASM=0: the one-bootstrap-per-workgroup mapping runs the compiler-scheduled kernel
     bool pbs_asm = true;  // TFA_PBS_ASM=0: the 8-wave mapping runs the compiler-scheduled kernel instead of the hand-scheduled loop
     // time of one round of workgroups over all CUs per mapping, microseconds: [0] 8 bootstraps per workgroup, [1] 4 per
     // workgroup, [2] one bootstrap per workgroup and one workgroup per CU, [3] the same with two workgroups per CU.
@@ -211,6 +213,7 @@ extern "C" int tfa_ctx_create(const tfa_params *p, int hip_device, tfa_ctx **out
     if (const char *t = getenv("TFA_TRACE")) ctx->trace = atoi(t) != 0;
     if (const char *t = getenv("TFA_KS_VALU")) ctx->ks_valu = atoi(t) != 0;
     if (const char *t = getenv("TFA_PBS_ASM")) ctx->pbs_asm = atoi(t) != 0;
+    if (const char *t = getenv("TFA_LAT_ASM")) ctx->lat_asm = atoi(t) != 0;
     if (const char *w = getenv("TFA_PBS_WAVES")) ctx->force_waves = (atoi(w) == 8 || atoi(w) == 4 || atoi(w) == 2 || atoi(w) == 1) ? atoi(w) : 0;
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     // per-lane twiddles e^{i pi t (1 + 4 r)/512}, [r][t]
@@ -233,6 +236,8 @@ extern "C" int tfa_ctx_create(const tfa_params *p, int hip_device, tfa_ctx **out
     HIPCHK(ctx, hipMemcpy(ctx->d_tw_lat, twl.data(), sizeof(c64) * 512, hipMemcpyHostToDevice));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_lat_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LatGeom<1>::kLdsBytes));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_lat_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LatGeom<2>::kLdsBytes));
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_lat_asm_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LatAsmGeom<1>::kLdsBytes));
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_lat_asm_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LatAsmGeom<2>::kLdsBytes));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bsk_convert_lat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLatConvertLdsBytes));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, PbsGeom<4>::kLdsBytes));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, PbsGeom<8>::kLdsBytes));
@@ -285,7 +290,10 @@ extern "C" int tfa_keys_upload(tfa_ctx *ctx, const uint32_t *bsk, const uint32_t
         HIPCHK(ctx, hipMalloc(&ctx->d_bsk_f, bsk_words / 2 * sizeof(c64) + kAsmKeySlackBytes));
         HIPCHK(ctx, hipMemset(reinterpret_cast<unsigned char *>(ctx->d_bsk_f) + bsk_words / 2 * sizeof(c64), 0, kAsmKeySlackBytes));
     }
-    if (!ctx->d_bsk_lat) HIPCHK(ctx, hipMalloc(&ctx->d_bsk_lat, bsk_words / 2 * sizeof(c64)));
+    if (!ctx->d_bsk_lat) {  // plus one step of slack: the hand-scheduled loop loads the key one step ahead without an end-of-key test
+        HIPCHK(ctx, hipMalloc(&ctx->d_bsk_lat, bsk_words / 2 * sizeof(c64) + kLatKeySlackBytes));
+        HIPCHK(ctx, hipMemset(reinterpret_cast<unsigned char *>(ctx->d_bsk_lat) + bsk_words / 2 * sizeof(c64), 0, kLatKeySlackBytes));
+    }
     if (!ctx->d_ksk) HIPCHK(ctx, hipMalloc(&ctx->d_ksk, (size_t)kN_ * p.ks_level * ctx->ksk_stride * sizeof(uint32_t)));
     // KSK rows padded to the pool stride
     HIPCHK(ctx, hipMemset(ctx->d_ksk, 0, (size_t)kN_ * p.ks_level * ctx->ksk_stride * sizeof(uint32_t)));
@@ -445,8 +453,14 @@ static void launch_variant(tfa_ctx *ctx, int variant, const uint32_t *in_base, u
     else if (variant == 4)
         hipLaunchKernelGGL(pbs_kernel<4>, dim3((count + 3) / 4), dim3(256), PbsGeom<4>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
                            ctx->d_bsk_f, ctx->d_tw, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
+    else if (variant == 2 && ctx->lat_asm)
+        hipLaunchKernelGGL(pbs_lat_asm_kernel<2>, dim3(count), dim3(256), LatAsmGeom<2>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
+                           ctx->d_bsk_lat, ctx->d_tw_lat, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
     else if (variant == 2)
         hipLaunchKernelGGL(pbs_lat_kernel<2>, dim3(count), dim3(256), LatGeom<2>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
+                           ctx->d_bsk_lat, ctx->d_tw_lat, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
+    else if (ctx->lat_asm)
+        hipLaunchKernelGGL(pbs_lat_asm_kernel<1>, dim3(count), dim3(256), LatAsmGeom<1>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
                            ctx->d_bsk_lat, ctx->d_tw_lat, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
     else
         hipLaunchKernelGGL(pbs_lat_kernel<1>, dim3(count), dim3(256), LatGeom<1>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,

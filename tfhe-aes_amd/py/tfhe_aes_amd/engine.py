@@ -56,6 +56,13 @@ def load_library():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise TfaError(f"HIP extension not built: {LIB_PATH} is missing (run `make -C tfhe-aes_amd`)")
+        # PyTorch ships its own copy of the HIP runtime: when the engine's library is loaded first, it binds the system
+        # copy and torch's later initialisation finds no GPU ("No HIP GPUs are available").  Importing torch first (when it
+        # is installed; the engine itself does not need it) makes both use the one already loaded.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = C.CDLL(LIB_PATH)
         _lib.tfa_last_error.restype = C.c_char_p
         _lib.tfa_bsk_words.restype = C.c_uint64

@@ -25,12 +25,12 @@ W, L = 8, 64
 
 
 class Machine:
-    def __init__(self, key_bytes):
+    def __init__(self, key_bytes, lds_bytes=None):
         self.v = np.zeros((256, W, L), np.uint32)
         self.s = np.zeros((110, W), np.uint32)
         self.m0 = np.zeros(W, np.uint32)
         self.scc = np.zeros(W, bool)
-        self.lds = np.zeros(G.K_LDS_BYTES + 64, np.uint8)
+        self.lds = np.zeros((lds_bytes or G.K_LDS_BYTES) + 64, np.uint8)
         self.key = key_bytes          # global memory image of the Fourier key; addresses are offsets into it
         self.count = {}
         # strict timing model: an LDS read delivers its registers, and an LDS-DMA row lands in the LDS, only at the
@@ -38,6 +38,7 @@ class Machine:
         # still in flight is an error
         self.lds_queue = []           # per LDS operation in flight: None (a write) or (first register, words [k][W][L])
         self.dma_queue = []           # (destination byte indices, data)
+        self.vm_queue = []            # global loads into registers in flight: (first register, words)
 
     # ---- operand access ----
     def dget(self, r):
@@ -124,6 +125,11 @@ class Machine:
                     done, self.dma_queue = self.dma_queue[:len(self.dma_queue) - keep], self.dma_queue[len(self.dma_queue) - keep:] if keep else []
                     for dst, data in done:
                         self.lds[dst] = data
+                    # (a kernel uses either LDS-DMA rows or register loads, so one vmcnt serves both queues here)
+                    done, self.vm_queue = self.vm_queue[:len(self.vm_queue) - keep], self.vm_queue[len(self.vm_queue) - keep:] if keep else []
+                    for r0, words in done:
+                        for k, wd in enumerate(words):
+                            self.v[r0 + k] = wd
                 continue
             if op == "s_barrier":
                 assert not any(item is not None and item[2] for item in self.lds_queue), "key reads in flight at a barrier: " + str(pc)
@@ -134,8 +140,12 @@ class Machine:
             for item in self.lds_queue:
                 if item is not None:
                     busy.update(range(item[0], item[0] + len(item[1])))
+            for r0, words in self.vm_queue:
+                busy.update(range(r0, r0 + len(words)))
             if busy:
                 used = {r for (kind, r) in G.regs_of(rest) if kind == "v"}
+                if op.startswith("global_load_dwordx4"):
+                    used = {r for (kind, r) in G.regs_of(a[1]) if kind == "v"}
                 if op.startswith("ds_read"):     # a younger read may overwrite an older one's destination: the LDS returns in order
                     used = {r for (kind, r) in G.regs_of(a[1]) if kind == "v"}
                 assert not (busy & used), "line %d touches v%s while its LDS read is in flight: %s" % (pc, sorted(busy & used), ln)
@@ -170,6 +180,8 @@ class Machine:
                 self.v[int(a[0][1:])] = self.src32(a[1]) ^ self.src32(a[2])
             elif op == "v_lshl_add_u32":
                 self.v[int(a[0][1:])] = (self.src32(a[1]) << self.src32(a[2])) + self.src32(a[3])
+            elif op == "v_lshlrev_b32":
+                self.v[int(a[0][1:])] = self.src32(a[2]) << self.src32(a[1])
             elif op == "v_lshrrev_b32":
                 self.v[int(a[0][1:])] = self.src32(a[2]) >> self.src32(a[1])
             elif op == "v_add3_u32":
@@ -214,17 +226,31 @@ class Machine:
                     r0 = int(re.match(r"v\[?(\d+)", dst).group(1))
                     self.lds_queue.append((r0, [words[..., k].copy() for k in range(n // 4)], addr_tok == "v%d" % G.V_KADDR))
                     continue
-            elif op in ("ds_write_b32", "ds_write_b64"):
+            elif op in ("ds_write_b32", "ds_write_b64", "ds_write_b128"):
                 addr_tok, data_tok = a[0], a[1].split()[0]
                 off = int(re.search(r"offset:(\d+)", rest).group(1)) if "offset:" in rest else 0
                 addr = self.src32(addr_tok) + np.uint32(off)
-                n = 4 if op == "ds_write_b32" else 8
+                n = {"ds_write_b32": 4, "ds_write_b64": 8, "ds_write_b128": 16}[op]
                 assert (addr % n == 0).all(), "misaligned LDS write"
                 r0 = int(re.match(r"v\[?(\d+)", data_tok).group(1))
                 words = np.stack([self.v[r0 + k] for k in range(n // 4)], axis=-1)
                 by = np.stack([(words >> np.uint32(8 * j)) & np.uint32(0xFF) for j in range(4)], axis=-1).astype(np.uint8)
                 self.lds_write(addr, by.reshape(W, L, n))
                 self.lds_queue.append(None)
+            elif op == "s_xor_b32":
+                self.sdst(a[0], self.ssrc(a[1]) ^ self.ssrc(a[2]))
+            elif op == "global_load_dwordx4":
+                # into registers: delivered at the s_waitcnt vmcnt that guarantees it, like an LDS read
+                r0 = int(re.match(r"v\[(\d+)", a[0]).group(1))
+                voff = self.src32(a[1]).astype(np.int64)
+                m = re.search(r"s\[(\d+):(\d+)\]", a[2])
+                r = int(m.group(1))
+                base = self.s[r].astype(np.int64) | (self.s[r + 1].astype(np.int64) << 32)
+                off = int(re.search(r"offset:(\d+)", rest).group(1)) if "offset:" in rest else 0
+                src = base[:, None] + voff + off
+                by = self.key[src[..., None] + np.arange(16)].reshape(W, L, 4, 4).astype(np.uint32)
+                words = by[..., 0] | (by[..., 1] << 8) | (by[..., 2] << 16) | (by[..., 3] << 24)
+                self.vm_queue.append((r0, [words[..., k].copy() for k in range(4)]))
             elif op == "global_load_lds_dwordx4":
                 voff = self.src32(a[0]).astype(np.int64)
                 m = re.fullmatch(r"s\[(\d+):(\d+)\]", a[1])

@@ -1,0 +1,424 @@
+#!/usr/bin/env python3
+"""Generator of the hand-scheduled step loop of pbs_lat_asm_kernel (gfx950 assembly): ONE bootstrap per workgroup,
+spread over its four waves, for stages too narrow to fill the GPU with one bootstrap per wave.
+
+Mapping, data layouts and results are those of pbs_lat_kernel<1> (csrc/pbs_lat_kernel.h): wave w owns polynomial w of
+the accumulator, lane L the coefficients L + 64 m; the size-256 transform runs over the 64 lanes as four radix-4 stages
+with three hand-overs through wave-private LDS; the waves publish their spectra (one barrier per step, two buffers
+alternating with the step parity) and wave w accumulates output polynomial w from all eight spectra and column w of
+the key, which it loads straight from global memory into registers one step ahead.
+
+What differs from the compiled kernel: every register and the order of the ~800 instructions of a step are chosen
+here; the two levels of the forward transform are interleaved stage by stage so that one level's hand-over travels
+under the other's butterfly; complex products are two multiplies and two multiply-adds; the twiddles of stages 1 and 2
+are read from a small LDS table when needed (registers: 128 key words + 28 twiddle words + data); the waits come
+from gen.place_waits().  tools/pbs_asm/lat_emu.py executes the emitted text on the CPU against the exact oracle.
+
+Register map (VGPR): v1 rotation write address | v2 rotation region base | v3 L | v4-7 hand-over base address of stage
+0-3 | v8 spectrum write base | v9-11 spectrum read bases of the polynomials (w + 1, 2, 3) & 3 | v12 key offset (16 L) |
+v13 stage-twiddle table address | v14-17 the four addresses above with the step parity added | v18 next rotation
+amount | v19-29 scratch | v30-31 1.5 * 2^52 | v32-39 accumulator | v40-55 twist | v56-67 stage-0 twiddles |
+v68-83 / v84-99 data of level 1 / 2 as (re, im) quads; the spectra read from the other waves | v100-115 output sums |
+v116-127 (+ whatever of v68-115 is free in a phase) temporaries | v128-255 key words [level][k][q], k = polynomial
+(w + k) & 3.   SGPR: s10 steps left | s11 address of a_tilde[i + 1] | s12 rotation amount | s13 parity offset |
+s14-15 scratch | s20-35 key pointers per (level, k) | s40+ constants.
+"""
+import math
+import os
+import struct
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import gen as G  # noqa: E402
+from gen import C, V, dreg, qreg  # noqa: E402
+
+# ---- geometry shared with pbs_lat_kernel.h / pbs_lat_asm_kernel.h ----
+K_FFT_ELEMS = 320
+K_FFT_BYTES = K_FFT_ELEMS * 16           # 5120
+K_WAVE_BYTES = 2 * K_FFT_BYTES
+K_RED_OFFSET = 4 * K_WAVE_BYTES          # 40960
+K_SPEC_BYTES = 4 * 2 * 4 * 64 * 16       # 32768 per buffer
+# PER_CU = 1: one workgroup per CU, two spectra buffers alternating with the step parity, one barrier per step.
+# PER_CU = 2: two workgroups share a CU (two waves per SIMD hide each other's waits); one spectra buffer and a second barrier
+# per step, so that both fit in the LDS.
+PER_CU = int(os.environ.get("PBS_LAT_PER_CU", "1"))
+K_SPEC_BUFFERS = 2 if PER_CU == 1 else 1
+K_A_OFFSET = K_RED_OFFSET + K_SPEC_BUFFERS * K_SPEC_BYTES
+K_TW_OFFSET = K_A_OFFSET + 1664          # stage-1 / stage-2 twiddles [s - 1][r][L] c64
+K_LDS_BYTES = K_TW_OFFSET + 6 * 1024
+STEP_KEY_BYTES = 2 * 4 * 4 * 4 * 64 * 16  # 131072
+MAGIC = 6755399441055744.0
+
+S_STEPS, S_ACUR, S_A, S_PAR, S_TMP = 10, 11, 12, 13, 14
+S_C2048 = 16
+S_TW = 36                                 # s[36:37] twiddle table in global memory (prologue only)
+S_KEY = 20                                # s[20 + 2 j : 21 + 2 j], j = lv * 4 + k
+S_CONST0 = 40
+
+V_ROTWR, V_ROTBASE, V_L = 1, 2, 3
+V_POS = [4, 5, 6, 7]
+V_SPECWR, V_SPECRD, V_KOFF, V_TWADDR = 8, [9, 10, 11], 12, 13
+V_SPECWR_CUR, V_SPECRD_CUR = 14, [15, 16, 17]
+V_AREAD = 18
+V_SCR = list(range(19, 30))
+V_MAGIC = 30
+V_ACC = 32
+R_TWIST, R_TW0 = 40, 56
+R_Z = [68, 84]
+R_OUT = 100
+R_T = 116
+R_KEY = 128
+
+
+def lat_pos(s, L, slot):
+    quarter = 64 >> (2 * s)
+    p0 = (L // quarter) * (4 * quarter) + (L & (quarter - 1))
+    return p0 + (p0 >> 2) + slot * (5 * quarter // 4 if s < 3 else 1)
+
+
+def slot_stride_bytes(s):
+    quarter = 64 >> (2 * s)
+    return 16 * (5 * quarter // 4 if s < 3 else 1)
+
+
+class Quad:
+    """A complex value in four consecutive registers (re lo, re hi, im lo, im hi)"""
+
+    def __init__(self, reg):
+        assert reg % 4 == 0
+        self.reg = reg
+
+    def c(self):
+        return C(V(self.reg), V(self.reg + 2))
+
+
+class Lat:
+    def __init__(self):
+        self.consts = G.Consts()
+        self.out = []
+
+    def e(self, s):
+        self.out.append(s)
+
+    def capture(self, fn, *args):
+        saved, self.out = self.out, []
+        fn(*args)
+        got, self.out = self.out, saved
+        return got
+
+    # ---- complex product with a twiddle in a register quad: z <- z * (c + i S s), four instructions, in place ----
+    def cmul(self, z, tw, S, scratch):
+        e = self.e
+        c, s_ = V(tw), V(tw + 2)
+        m1, m2 = scratch, scratch + 2
+        e("v_mul_f64 %s, %s, %s" % (dreg(m1), dreg(z + 2), s_.s()))
+        e("v_mul_f64 %s, %s, %s" % (dreg(m2), dreg(z), s_.s()))
+        e("v_fma_f64 %s, %s, %s, %s%s" % (dreg(z), dreg(z), c.s(), "-" if S > 0 else "", dreg(m1)))
+        e("v_fma_f64 %s, %s, %s, %s%s" % (dreg(z + 2), dreg(z + 2), c.s(), "" if S > 0 else "-", dreg(m2)))
+
+    def dft4(self, zbase, S, pool_regs):
+        """radix-4 butterfly on the four quads at zbase, in place (output r in quad r)"""
+        pool = G.Pool(pool_regs)
+        st = G.Stream(self, pool)
+        st.g = self
+        z = [C(V(zbase + 4 * q), V(zbase + 4 * q + 2)) for q in range(4)]
+        outs = [(zbase + 4 * q, zbase + 4 * q + 2) for q in range(4)]
+        G.dft4(st, z, S, outs)
+        self.out.extend(st.ins)
+
+    # ---- hand-over between stages ----
+    def ho_write(self, zbase, lv, s):
+        for r in range(4):
+            self.e("ds_write_b128 v%d, %s offset:%d" % (V_POS[s], qreg(zbase + 4 * r), lv * K_FFT_BYTES + r * slot_stride_bytes(s)))
+
+    def ho_read(self, zbase, lv, s):
+        for q in range(4):
+            self.e("ds_read_b128 %s, v%d offset:%d" % (qreg(zbase + 4 * q), V_POS[s], lv * K_FFT_BYTES + q * slot_stride_bytes(s)))
+
+    def tw_read(self, s, regs):
+        """the three twiddles of stage s (1 or 2) into three quads"""
+        for r in range(3):
+            self.e("ds_read_b128 %s, v%d offset:%d" % (qreg(regs[r]), V_TWADDR, ((s - 1) * 3 + r) * 1024))
+
+    # ---- the step ----
+    def rotate_decompose(self):
+        e = self.e
+        vb, x, ad = V_SCR[0], V_SCR[1], V_SCR[2]
+        rk = [R_T + m for m in range(8)]
+        e("v_subrev_u32 v%d, s%d, v%d" % (vb, S_A, V_L))                # L - a
+        for m in range(8):
+            e("v_add_u32 v%d, %d, v%d" % (x, 64 * m, vb))
+            e("v_and_b32 v%d, 0x1ff, v%d" % (ad, x))
+            e("v_lshl_add_u32 v%d, v%d, 2, v%d" % (ad, ad, V_ROTBASE))
+            e("ds_read_b32 v%d, v%d" % (rk[m], ad))
+        sg, ng, y, s_, u, w = V_SCR[3], V_SCR[4], V_SCR[5], V_SCR[6], V_SCR[7], V_SCR[8]
+        for m in range(8):
+            v = rk[m]
+            q, part = m & 3, 0 if m < 4 else 2
+            e("v_add_u32 v%d, %d, v%d" % (x, 64 * m, vb))
+            e("v_bfe_i32 v%d, v%d, 9, 1" % (sg, x))
+            e("v_bfe_u32 v%d, v%d, 9, 1" % (ng, x))
+            e("v_xor_b32 v%d, v%d, v%d" % (y, v, sg))
+            e("v_sub_u32 v%d, v%d, v%d" % (ng, ng, V_ACC + m))
+            e("v_add3_u32 v%d, v%d, v%d, s%d" % (y, y, ng, S_C2048))
+            e("v_lshrrev_b32 v%d, 12, v%d" % (s_, y))
+            e("v_lshrrev_b32 v%d, 31, v%d" % (u, y))
+            e("v_add_u32 v%d, v%d, v%d" % (u, s_, u))
+            e("v_add_u32 v%d, 0x7fdff, v%d" % (w, u))
+            e("v_bfe_u32 v%d, v%d, 10, 10" % (w, w))
+            e("v_add_u32 v%d, 0xfffffe01, v%d" % (w, w))
+            e("v_cvt_f64_i32 %s, v%d" % (dreg(R_Z[0] + 4 * q + part), w))
+            e("v_add_u32 v%d, 0x1ff, v%d" % (u, u))
+            e("v_and_b32 v%d, 0xfffffc00, v%d" % (u, u))
+            e("v_sub_u32 v%d, v%d, v%d" % (u, s_, u))
+            e("v_cvt_f64_i32 %s, v%d" % (dreg(R_Z[1] + 4 * q + part), u))
+
+    def forward(self):
+        """both levels, interleaved stage by stage: one level's hand-over travels under the other's butterfly.
+        Temporaries: the output-sum registers (free until the products) for the butterflies, v116-127 for the three
+        stage twiddles, v20-23 (the integer work is over) for the complex products."""
+        pool = list(range(R_OUT, R_OUT + 16, 2))
+        twq = [R_T, R_T + 4, R_T + 8]
+        scr = 20
+        self.tw_read(1, twq)                               # stage 1's twiddles are on their way through the twist and stage 0
+        for lv in (0, 1):
+            for q in range(4):
+                self.cmul(R_Z[lv] + 4 * q, R_TWIST + 4 * q, 1, scr)
+        for s in range(4):
+            for lv in (0, 1):
+                z = R_Z[lv]
+                self.dft4(z, 1, pool)
+                if s == 3:
+                    continue
+                for r in range(3):
+                    tw = R_TW0 + 4 * r if s == 0 else twq[r]
+                    self.cmul(z + 4 * (r + 1), tw, 1, scr)
+                if s == 1 and lv == 1:
+                    self.tw_read(2, twq)                   # stage 1 has used its twiddles: the registers take stage 2's
+                self.ho_write(z, lv, s)
+                self.ho_read(z, lv, s + 1)
+
+    def publish_and_own_term(self):
+        e = self.e
+        for lv in (0, 1):
+            for q in range(4):
+                e("ds_write_b128 v%d, %s offset:%d" % (V_SPECWR_CUR, qreg(R_Z[lv] + 4 * q), (lv * 4 + q) * 1024))
+        e("s_waitcnt vmcnt(0)")                            # the key words of this step (loaded during the previous one)
+        # own polynomial (k = 0): its spectra are still in registers; level 1 initialises the sums
+        self.mac_block(R_Z[0], 0, 0, first=True)
+
+    def mac_block(self, f, lv, k, first):
+        """out[q] += f[q] * key[lv][k][q] for the four q: eight independent chains, two rounds"""
+        e = self.e
+        for q in range(4):
+            orr, oi = dreg(R_OUT + 4 * q), dreg(R_OUT + 4 * q + 2)
+            fx, key = dreg(f + 4 * q), R_KEY + ((lv * 4 + k) * 4 + q) * 4
+            if first:
+                e("v_mul_f64 %s, %s, %s" % (orr, fx, dreg(key)))
+                e("v_mul_f64 %s, %s, %s" % (oi, fx, dreg(key + 2)))
+            else:
+                e("v_fma_f64 %s, %s, %s, %s" % (orr, fx, dreg(key), orr))
+                e("v_fma_f64 %s, %s, %s, %s" % (oi, fx, dreg(key + 2), oi))
+        for q in range(4):
+            orr, oi = dreg(R_OUT + 4 * q), dreg(R_OUT + 4 * q + 2)
+            fy, key = dreg(f + 4 * q + 2), R_KEY + ((lv * 4 + k) * 4 + q) * 4
+            e("v_fma_f64 %s, -%s, %s, %s" % (orr, fy, dreg(key + 2), orr))
+            e("v_fma_f64 %s, %s, %s, %s" % (oi, fy, dreg(key), oi))
+
+    def spec_read(self, lv, k):
+        for q in range(4):
+            self.e("ds_read_b128 %s, v%d offset:%d" % (qreg(R_Z[lv] + 4 * q), V_SPECRD_CUR[k - 1], (lv * 4 + q) * 1024))
+
+    def others(self):
+        """the other three polynomials' spectra land in the registers of the own data (consumed by now), half a
+        polynomial at a time: the next half is requested as soon as the products have released its registers"""
+        self.spec_read(0, 1)
+        self.mac_block(R_Z[1], 1, 0, first=False)          # the own level-2 term covers the first reads' latency
+        self.spec_read(1, 1)
+        for k in (1, 2, 3):
+            self.mac_block(R_Z[0], 0, k, first=False)
+            if k < 3:
+                self.spec_read(0, k + 1)
+            self.mac_block(R_Z[1], 1, k, first=False)
+            if k < 3:
+                self.spec_read(1, k + 1)
+
+    def key_loads(self, k):
+        """next step's key words of polynomial slot k (both levels) replace the ones just consumed"""
+        e = self.e
+        for lv in (0, 1):
+            j = lv * 4 + k
+            for q in range(4):
+                e("global_load_dwordx4 %s, v%d, s[%d:%d] offset:%d" % (qreg(R_KEY + (j * 4 + q) * 4), V_KOFF, S_KEY + 2 * j, S_KEY + 2 * j + 1, q * 1024))
+
+    def inverse(self):
+        e = self.e
+        z = R_OUT
+        pool = [68, 70, 72, 74, 76, 78, 80, 82]           # the spectra registers are free again
+        scr = 84
+        twq = [88, 92, 96]
+        tw1 = [R_T, R_T + 4, R_T + 8]
+        self.tw_read(2, twq)
+        self.tw_read(1, tw1)
+        for s in (3, 2, 1, 0):
+            self.key_loads(3 - s)                          # a quarter of the next step's key before each stage
+            if s < 3:
+                for r in range(3):
+                    tw = R_TW0 + 4 * r if s == 0 else (twq[r] if s == 2 else tw1[r])
+                    self.cmul(z + 4 * (r + 1), tw, -1, scr)
+            self.dft4(z, -1, pool)
+            if s > 0:
+                self.ho_write(z, 0, s)
+                self.ho_read(z, 0, s - 1)
+        for q in range(4):
+            self.cmul(z + 4 * q, R_TWIST + 4 * q, -1, scr)
+
+    def accumulate(self):
+        e = self.e
+        t = 68
+        for q in range(4):
+            for part, m in ((0, q), (2, q + 4)):
+                e("v_add_f64 %s, %s, %s" % (dreg(t), dreg(R_OUT + 4 * q + part), dreg(V_MAGIC)))
+                e("v_add_u32 v%d, v%d, v%d" % (V_ACC + m, V_ACC + m, t))
+                e("ds_write_b32 v%d, v%d offset:%d" % (V_ROTWR, V_ACC + m, 256 * m))
+                t += 2
+
+    def step(self):
+        e = self.e
+        self.rotate_decompose()
+        self.forward()
+        # this step's parity: spectrum addresses
+        e("v_add_u32 v%d, s%d, v%d" % (V_SPECWR_CUR, S_PAR, V_SPECWR))
+        for k in range(3):
+            e("v_add_u32 v%d, s%d, v%d" % (V_SPECRD_CUR[k], S_PAR, V_SPECRD[k]))
+        self.publish_and_own_term()
+        e(";drain")                                        # every wave's spectrum stores are done before any wave reads them
+        e("s_barrier")
+        self.others()
+        if K_SPEC_BUFFERS == 1:
+            e("s_barrier")                                 # every wave has read the spectra before the next step's are stored
+        # next rotation amount
+        e("v_mov_b32 v%d, s%d" % (V_SCR[0], S_ACUR))
+        e("ds_read_u16 v%d, v%d" % (V_AREAD, V_SCR[0]))
+        self.advance_key_pointers()
+        self.inverse()
+        e("v_readfirstlane_b32 s%d, v%d" % (S_A, V_AREAD))
+        self.accumulate()
+
+    def advance_key_pointers(self):
+        for j in range(8):
+            self.e("s_add_u32 s%d, s%d, 0x%x" % (S_KEY + 2 * j, S_KEY + 2 * j, STEP_KEY_BYTES))
+            self.e("s_addc_u32 s%d, s%d, 0" % (S_KEY + 2 * j + 1, S_KEY + 2 * j + 1))
+
+    def build(self):
+        e = self.e
+        body = Lat.__new__(Lat)
+        body.consts, body.out = self.consts, []
+        body.step()
+        mbits = struct.unpack("<Q", struct.pack("<d", MAGIC))[0]
+        e("s_mov_b32 s%d, 0x800" % S_C2048)
+        e("v_mov_b32 v%d, 0x%x" % (V_MAGIC, mbits & 0xFFFFFFFF))
+        e("v_mov_b32 v%d, 0x%x" % (V_MAGIC + 1, mbits >> 32))
+        for j, val in enumerate(self.consts.vals):
+            bits = struct.unpack("<Q", struct.pack("<d", val))[0]
+            e("s_mov_b32 s%d, 0x%x" % (S_CONST0 + 2 * j, bits & 0xFFFFFFFF))
+            e("s_mov_b32 s%d, 0x%x" % (S_CONST0 + 2 * j + 1, bits >> 32))
+        # twist e^{i pi (L + 64 q) / 512} and the stage-0 twiddles e^{2 pi i L (r + 1) / 256} from the table in global memory
+        # (s[36:37]: [0, 256) = e^{i pi n / 512}, [256, 512) = e^{2 pi i k / 256}); they stay in registers for the whole loop
+        for q in range(4):
+            e("global_load_dwordx4 %s, v%d, s[%d:%d] offset:%d" % (qreg(R_TWIST + 4 * q), V_KOFF, S_TW, S_TW + 1, 1024 * q))
+        e("s_add_u32 s%d, s%d, 0x1000" % (S_TW, S_TW))
+        e("s_addc_u32 s%d, s%d, 0" % (S_TW + 1, S_TW + 1))
+        for r in range(3):
+            t = V_SCR[r]
+            if r == 0:
+                e("v_mov_b32 v%d, v%d" % (t, V_L))
+            elif r == 1:
+                e("v_lshlrev_b32 v%d, 1, v%d" % (t, V_L))
+            else:
+                e("v_lshl_add_u32 v%d, v%d, 1, v%d" % (t, V_L, V_L))
+            e("v_and_b32 v%d, 0xff, v%d" % (t, t))
+            e("v_lshlrev_b32 v%d, 4, v%d" % (t, t))
+            e("global_load_dwordx4 %s, v%d, s[%d:%d]" % (qreg(R_TW0 + 4 * r), t, S_TW, S_TW + 1))
+        # the first step's key words
+        for k in range(4):
+            self.key_loads(k)
+        e("s_waitcnt vmcnt(0)")                            # the twiddles are used right away
+        e("L_lstep%=:")
+        self.out.extend(place_waits_lat(body.out))
+        if K_SPEC_BUFFERS == 2:
+            e("s_xor_b32 s%d, s%d, 0x%x" % (S_PAR, S_PAR, K_SPEC_BYTES))
+        e("s_add_u32 s%d, s%d, 2" % (S_ACUR, S_ACUR))
+        e("s_sub_u32 s%d, s%d, 1" % (S_STEPS, S_STEPS))
+        e("s_cmp_lg_u32 s%d, 0" % S_STEPS)
+        e("s_cbranch_scc1 L_lstep%=")
+        e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+        return self.out
+
+
+def place_waits_lat(lines):
+    """gen.place_waits() with this kernel's conventions: the key loads (vmcnt) are waited for by the explicit
+    s_waitcnt vmcnt(0) in front of the products and are not tracked; a barrier needs no LDS drain here (the
+    spectra it publishes are stores)."""
+    saved = G.V_KADDR
+    G.V_KADDR = 1 << 20          # no register: nothing counts as a ring read
+    try:
+        out = G.place_waits(list(lines))
+    finally:
+        G.V_KADDR = saved
+    return ["s_waitcnt lgkmcnt(0)" if ln == ";drain" else ln for ln in out]
+
+
+def experiment_filter(lines, flags):
+    """timing experiments (results become garbage): nokey drops the key loads of the loop, nobar the barrier, nowait the
+    LDS waits, noho the hand-overs between stages, nospec the reads of the other waves' spectra"""
+    out, in_loop = [], False
+    for ln in lines:
+        op = ln.split()[0]
+        if ln.endswith(":"):
+            in_loop = True
+        if in_loop and "nokey" in flags and op == "global_load_dwordx4":
+            continue
+        if "nobar" in flags and op == "s_barrier":
+            continue
+        if "nowait" in flags and ln.startswith("s_waitcnt lgkmcnt("):
+            continue
+        if "noho" in flags and op in ("ds_write_b128", "ds_read_b128") and any(", v%d " % r in ln + " " or ln.startswith("ds_write_b128 v%d," % r) for r in V_POS):
+            continue
+        if "nospec" in flags and op == "ds_read_b128" and any(", v%d " % r in ln + " " for r in V_SPECRD_CUR):
+            continue
+        out.append(ln)
+    return out
+
+
+def main():
+    g = Lat()
+    lines = g.build()
+    flags = [f for f in os.environ.get("PBS_ASM_EXP", "").split(",") if f]
+    if flags:
+        lines = experiment_filter(lines, flags)
+    v, s = G.clobbers(lines)
+    inputs_v = set([V_ROTWR, V_ROTBASE, V_L] + V_POS + [V_SPECWR] + V_SPECRD + [V_KOFF, V_TWADDR]) | set(range(V_ACC, V_ACC + 8))
+    inputs_s = set([S_STEPS, S_ACUR, S_A, S_PAR, S_TW, S_TW + 1]) | set(range(S_KEY, S_KEY + 16))
+    assert 0 not in v and not (set(range(0, 8)) & set(s)), "v0 / s0-s7 belong to the compiler"
+    cl = ['"v%d"' % r for r in v if r not in inputs_v] + ['"s%d"' % r for r in s if r not in inputs_s]
+    out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "..", "..", "tfhe-aes_amd", "csrc", "pbs_lat_asm_loop.inc")
+    with open(out_path, "w") as f:
+        f.write("// GENERATED by tools/pbs_asm/lat_gen.py - do not edit.  %d instructions per blind-rotation step.\n" % len([x for x in lines if not x.endswith(":")]))
+        f.write("#define TFA_LAT_ASM%s_BODY \\\n" % ("" if PER_CU == 1 else "2"))
+        for ln in lines:
+            f.write('    "%s\\n\\t" \\\n' % ln)
+        f.write('    ""\n')
+        f.write("#define TFA_LAT_ASM%s_CLOBBERS %s\n" % ("" if PER_CU == 1 else "2", ", ".join(cl + ['"memory"', '"scc"', '"vcc"'])))
+    stats = {}
+    for ln in lines:
+        op = ln.split()[0]
+        stats[op] = stats.get(op, 0) + 1
+    print("lines", len(lines), "VALU", sum(n for op, n in stats.items() if op.startswith("v_")), "f64", sum(n for op, n in stats.items() if "f64" in op),
+          "ds", sum(n for op, n in stats.items() if op.startswith("ds_")), "global", stats.get("global_load_dwordx4", 0))
+    return lines
+
+
+if __name__ == "__main__":
+    main()
