@@ -22,4 +22,51 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
             widest = max(g for g, _ in v)
             vals = [x for g, x in v if g == widest]
             out.setdefault(k, {})[f"{c}@{n}"] = sum(vals) / len(vals)
-print(json.dumps(out, indent=1, sort_keys=True))
+
+
+def derived(c, waves_per_bootstrap, steps=805, n=8192, ratios_only=False):
+    """ratios the text quotes; SQ_* wave counters share one unit, so their ratios need no conversion"""
+    wc = c["SQ_WAVE_CYCLES@%d" % n]
+    d = {k + "/SQ_WAVE_CYCLES": round(c["%s@%d" % (k, n)] / wc, 4)
+         for k in ("SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS")}
+    d["lds_bank_conflict_cycles/lds_active_cycles"] = round(c["SQ_LDS_BANK_CONFLICT@%d" % n] / c["SQ_LDS_IDX_ACTIVE@%d" % n], 4)
+    if ratios_only:
+        return d
+    per = n * waves_per_bootstrap * steps
+    d["valu_instructions_per_wave_step"] = round(c["SQ_INSTS_VALU@%d" % n] / per, 1)
+    d["lds_instructions_per_wave_step"] = round(c["SQ_INSTS_LDS@%d" % n] / per, 1)
+    if "FETCH_SIZE@65536" in c:
+        d["hbm_bytes_per_65536_launch"] = int((2 * c["FETCH_SIZE@65536"] + c["WRITE_SIZE@65536"]) * 1024)
+    return d
+
+
+def fp64_mix(lines):
+    ops = [ln.split()[0] for ln in lines if not ln.endswith(":")]
+    n = {k: sum(1 for o in ops if o.startswith(k)) for k in ("v_fma_f64", "v_add_f64", "v_mul_f64")}
+    n["fma_share"] = round(n["v_fma_f64"] / sum(n.values()), 3)
+    n["source"] = "instruction counts of the generated loop (tools/pbs_asm)"
+    return n
+
+
+res = {"note": "rocprofv3 --pmc, separate passes (tools/profile_round.sh), reduced by tools/pmc_summary.py: mean per dispatch over the "
+               "workload's launches (the round-time calibration's launches are left out). FETCH_SIZE/WRITE_SIZE in KiB as reported "
+               "(gfx950: double FETCH_SIZE for 16-byte-per-lane reads). @N = bootstraps per dispatch (tools/prof_pbs.py N). "
+               "SQ_* wave counters in quad-cycles. The one-bootstrap-per-workgroup kernels (pbs_lat_*) are launched here only by the "
+               "round-time calibration (one round of workgroups, 100 and 300 steps), so only their ratios are meaningful.",
+       "counters_current_kernels": out}
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "pbs_asm"))
+for k, c in out.items():
+    try:
+        if "pbs_asm_kernel<0>" in k:
+            import gen
+            res["derived_pbs_asm_kernel"] = derived(c, 1)
+            res["derived_pbs_asm_kernel"]["fp64_instructions_per_wave_step"] = fp64_mix(gen.Loop().build())
+        elif "pbs_lat_asm_kernel<1>" in k:
+            import lat_gen
+            res["derived_pbs_lat_asm_kernel_1"] = derived(c, 4, ratios_only=True)
+            res["derived_pbs_lat_asm_kernel_1"]["fp64_instructions_per_wave_step"] = fp64_mix(lat_gen.Lat().build())
+        elif "pbs_lat_asm_kernel<2>" in k:
+            res["derived_pbs_lat_asm_kernel_2"] = derived(c, 4, ratios_only=True)
+    except KeyError:
+        pass
+print(json.dumps(res, indent=1, sort_keys=True))
