@@ -47,6 +47,13 @@ S_TMP = 14      # s[14:15] scratch pair (DMA row pointer)
 S_C2048 = 16
 S_CONST0 = 18   # fp64 constants from here, in pairs
 
+
+def const_reg(index):
+    """first scalar register of constant pair `index`; s[32:33] are left alone (the compiler reserves s32 as stack pointer
+    and warns about an asm statement that clobbers it)"""
+    r = S_CONST0 + 2 * index
+    return r + 2 if r >= 32 else r
+
 V_ROTWR, V_ROTBASE, V_T = 1, 2, 3
 V_TRWR = [4, 5, 6, 7]            # exchange store address for element groups r >> 2
 V_TRRD = [8, 9, 10, 11]          # exchange row-read address for words (w & 3), offset 64 * (w >> 2)
@@ -86,7 +93,7 @@ class Consts:
         if key not in self.idx:
             self.idx[key] = len(self.vals)
             self.vals.append(key)
-        r = S_CONST0 + 2 * self.idx[key]
+        r = const_reg(self.idx[key])
         assert r + 1 <= 101, "out of scalar registers for constants"
         return "s[%d:%d]" % (r, r + 1)
 
@@ -604,8 +611,8 @@ class Loop:
         e("s_mov_b32 s%d, 0x800" % S_C2048)
         for j, val in enumerate(self.consts.vals):
             bits = struct.unpack("<Q", struct.pack("<d", val))[0]
-            e("s_mov_b32 s%d, 0x%x" % (S_CONST0 + 2 * j, bits & 0xFFFFFFFF))
-            e("s_mov_b32 s%d, 0x%x" % (S_CONST0 + 2 * j + 1, bits >> 32))
+            e("s_mov_b32 s%d, 0x%x" % (const_reg(j), bits & 0xFFFFFFFF))
+            e("s_mov_b32 s%d, 0x%x" % (const_reg(j) + 1, bits >> 32))
         mbits = struct.unpack("<Q", struct.pack("<d", MAGIC))[0]
         e("v_mov_b32 v%d, 0x%x" % (V_MAGIC, mbits & 0xFFFFFFFF))
         e("v_mov_b32 v%d, 0x%x" % (V_MAGIC + 1, mbits >> 32))

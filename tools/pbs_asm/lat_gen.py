@@ -54,7 +54,6 @@ S_STEPS, S_ACUR, S_A, S_PAR, S_TMP = 10, 11, 12, 13, 14
 S_C2048 = 16
 S_TW = 36                                 # s[36:37] twiddle table in global memory (prologue only)
 S_KEY = 20                                # s[20 + 2 j : 21 + 2 j], j = lv * 4 + k
-S_CONST0 = 40
 
 V_ROTWR, V_ROTBASE, V_L = 1, 2, 3
 V_POS = [4, 5, 6, 7]
@@ -320,10 +319,7 @@ class Lat:
         e("s_mov_b32 s%d, 0x800" % S_C2048)
         e("v_mov_b32 v%d, 0x%x" % (V_MAGIC, mbits & 0xFFFFFFFF))
         e("v_mov_b32 v%d, 0x%x" % (V_MAGIC + 1, mbits >> 32))
-        for j, val in enumerate(self.consts.vals):
-            bits = struct.unpack("<Q", struct.pack("<d", val))[0]
-            e("s_mov_b32 s%d, 0x%x" % (S_CONST0 + 2 * j, bits & 0xFFFFFFFF))
-            e("s_mov_b32 s%d, 0x%x" % (S_CONST0 + 2 * j + 1, bits >> 32))
+        assert not self.consts.vals, "this loop folds no scalar constants (all its factors are per-lane twiddles)"
         # twist e^{i pi (L + 64 q) / 512} and the stage-0 twiddles e^{2 pi i L (r + 1) / 256} from the table in global memory
         # (s[36:37]: [0, 256) = e^{i pi n / 512}, [256, 512) = e^{2 pi i k / 256}); they stay in registers for the whole loop
         for q in range(4):
