@@ -35,6 +35,46 @@ def kernel_sequence(v, jj, acc):
     return d1.astype(np.int64), d2.astype(np.int64)
 
 
+def asm_sequence(v, r, m, acc):
+    """the hand-scheduled loop's version (rotate_decompose in tools/pbs_asm/gen.py): negated accumulator in registers and
+    rotation buffer, wrap / sign taken from one mask per lane; r = t - a, m = coefficient group, jj = r + 16 m"""
+    n_src, n_own = np.uint32(0) - v.astype(np.uint32), np.uint32(0) - acc.astype(np.uint32)
+    r = r.astype(np.uint32)
+    with np.errstate(over="ignore"):
+        e = ((~r) >> np.uint32(4)) & np.uint32(31)
+        fw = np.uint32(0xFFFFFFFE) << e                                   # bit m: the index wrapped past 511
+        s0 = np.where((r >> np.uint32(9)) & np.uint32(1), np.uint32(0xFFFFFFFF), np.uint32(0))
+        fs = ~(fw ^ s0)
+        wrapped = (fw >> m.astype(np.uint32)) & np.uint32(1)
+        idx = (r & np.uint32(511)) + np.uint32(16) * m.astype(np.uint32) - np.uint32(512) * wrapped
+        sg = np.where((fs >> m.astype(np.uint32)) & np.uint32(1), np.uint32(0xFFFFFFFF), np.uint32(0))
+        c = (sg & np.uint32(1)) + n_own + np.uint32(2048)
+        y = (n_src ^ sg) + c
+        s, b19 = y >> np.uint32(12), y >> np.uint32(31)
+        u = s + b19 + np.uint32(511)
+        d1 = (((u + np.uint32(511 << 10)) >> np.uint32(10)) & np.uint32(1023)).astype(np.int32) - 511
+        d2 = (s - (u & np.uint32(0xFFFFFC00))).astype(np.int32)
+    return d1.astype(np.int64), d2.astype(np.int64), idx
+
+
+def test_asm_sequence():
+    rng = np.random.default_rng(12)
+    n = 1 << 21
+    v = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    acc = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    r = rng.integers(-1023, 16, n).astype(np.int32)                       # t - a, t in [0, 16), a in [0, 1024)
+    m = rng.integers(0, 32, n).astype(np.int32)
+    for rr, mm in ((r, m), (np.repeat(np.arange(-1023, 16, dtype=np.int32), 32), np.tile(np.arange(32, dtype=np.int32), 1039))):
+        k = len(rr)
+        jj = rr + 16 * mm
+        with np.errstate(over="ignore"):
+            x = np.where((jj >> 9) & 1, np.uint32(0) - v[:k], v[:k]) - acc[:k]
+        e1, e2 = literal_rule(x)
+        g1, g2, idx = asm_sequence(v[:k], rr, mm, acc[:k])
+        assert (e1 == g1).all() and (e2 == g2).all()
+        assert (idx == (jj & 511).astype(np.uint32)).all()                # the address it reads is the rotated index
+
+
 def check(v, jj, acc):
     with np.errstate(over="ignore"):
         x = np.where((jj >> 9) & 1, np.uint32(0) - v, v) - acc

@@ -178,6 +178,12 @@ class Machine:
                 self.v[int(a[0][1:])] = self.src32(a[1]) & self.src32(a[2])
             elif op == "v_xor_b32":
                 self.v[int(a[0][1:])] = self.src32(a[1]) ^ self.src32(a[2])
+            elif op == "v_xnor_b32":
+                self.v[int(a[0][1:])] = ~(self.src32(a[1]) ^ self.src32(a[2]))
+            elif op == "v_not_b32":
+                self.v[int(a[0][1:])] = ~self.src32(a[1])
+            elif op == "v_xad_u32":
+                self.v[int(a[0][1:])] = (self.src32(a[1]) ^ self.src32(a[2])) + self.src32(a[3])
             elif op == "v_lshl_add_u32":
                 self.v[int(a[0][1:])] = (self.src32(a[1]) << self.src32(a[2])) + self.src32(a[3])
             elif op == "v_lshlrev_b32":
@@ -311,7 +317,8 @@ def main():
         b_tilde = int(a_tilde[w, n])
         for m in range(32):
             jj = 16 * m + t + b_tilde
-            M.v[G.V_ACC + m][w] = np.where(g == 3, np.where((jj >> 9) & 1, 0xE0000000, 0x20000000), 0).astype(np.uint32)
+            # the loop keeps the accumulator negated, in its registers and in the rotation buffer
+            M.v[G.V_ACC + m][w] = np.uint32(0) - np.where(g == 3, np.where((jj >> 9) & 1, 0xE0000000, 0x20000000), 0).astype(np.uint32)
         # accumulator into the rotation buffer, a_tilde into its LDS array
         for m in range(32):
             addr = M.v[G.V_ROTWR][w] + 64 * m
@@ -346,7 +353,7 @@ def main():
         ref = o.blind_rotate(bsk, None, cts[w], steps)       # [4][512]
         got = np.zeros((4, 512), np.uint32)
         for m in range(32):
-            got[g, 16 * m + t] = M.v[G.V_ACC + m][w]
+            got[g, 16 * m + t] = np.uint32(0) - M.v[G.V_ACC + m][w]
         diff = (got != ref).sum()
         bad += int(diff)
         if diff:

@@ -45,6 +45,7 @@ S_A = 12        # current rotation amount
 S_M0ROW = 13    # LDS byte address of this wave's first DMA row in ring slot 0
 S_TMP = 14      # s[14:15] scratch pair (DMA row pointer)
 S_C2048 = 16
+S_C511 = 17
 S_CONST0 = 18   # fp64 constants from here, in pairs
 
 
@@ -324,35 +325,45 @@ class Loop:
     # ---- rotation + decomposition -------------------------------------------------------------------------------------
     def rotate_decompose(self):
         """d = acc * X^a - acc, both digits of every coefficient as doubles: level 1 -> array A, level 2 -> array B
-        (element n1 real part = coefficient 16 n1 + t, imaginary part = coefficient 16 n1 + t + 256).  The accumulator
-        already sits in the rotation buffer (written by the previous step's tail, or by the prologue)."""
+        (element n1 real part = coefficient 16 n1 + t, imaginary part = coefficient 16 n1 + t + 256).
+
+        Registers and rotation buffer hold the NEGATED accumulator n = -acc (the buffer was written by the previous
+        step's tail, or by the prologue).  With r = t - a, coefficient 16 m + t of acc * X^a is sign * acc[(r + 16 m) & 511],
+        sign = -1 where bit 9 of r + 16 m is set.  Along m a lane's index wraps past 511 at most once, at
+        m = ((511 - (r & 511)) >> 4) + 1, and the sign changes there and only there: one mask per lane and step (bit m = wrapped)
+        gives the read address (base - 2048 bytes once wrapped) and the sign of every coefficient with a bit-field extract
+        each, instead of recomputing r + 16 m twice per coefficient."""
         e = self.e
-        vb, x, ad = V_SCR[0], V_SCR[1], V_SCR[2]
-        e("v_subrev_u32 v%d, s%d, v%d" % (vb, S_A, V_T))                # t - a
+        fw, fs, a0, tmp = V_SCR[0], V_SCR[1], V_SCR[2], V_SCR[3]
+        e("v_subrev_u32 v%d, s%d, v%d" % (tmp, S_A, V_T))                # r = t - a
+        e("v_not_b32 v%d, v%d" % (fw, tmp))
+        e("v_bfe_u32 v%d, v%d, 4, 5" % (fw, fw))                          # (511 - (r & 511)) >> 4
+        e("v_lshlrev_b32 v%d, v%d, -2" % (fw, fw))               # bit m set: index wrapped
+        e("v_bfe_i32 v%d, v%d, 9, 1" % (fs, tmp))
+        e("v_xnor_b32 v%d, v%d, v%d" % (fs, fw, fs))                      # bit m set: sign = +1, the negated n[src] enters
+        e("v_and_b32 v%d, 0x1ff, v%d" % (tmp, tmp))
+        e("v_lshl_add_u32 v%d, v%d, 2, v%d" % (a0, tmp, V_ROTBASE))
         for m in range(32):
-            e("v_add_u32 v%d, %d, v%d" % (x, 16 * m, vb))
-            e("v_and_b32 v%d, 0x1ff, v%d" % (ad, x))
-            e("v_lshl_add_u32 v%d, v%d, 2, v%d" % (ad, ad, V_ROTBASE))
-            e("ds_read_b32 v%d, v%d" % (R_K + m, ad))
+            e("v_bfe_i32 v%d, v%d, %d, 1" % (tmp, fw, m))
+            e("v_lshl_add_u32 v%d, v%d, 11, v%d" % (tmp, tmp, a0))      # a0 - 2048 once wrapped
+            e("ds_read_b32 v%d, v%d offset:%d" % (R_K + m, tmp, 64 * m))
         # the m-th read has returned when at most 31 - m younger ones are in flight (the counter saturates at 15)
-        sg, ng, y, s_, u, w = V_SCR[3], V_SCR[4], V_SCR[5], V_SCR[6], V_SCR[7], V_SCR[8]
+        sg, c, y, s_, u, w = V_SCR[3], V_SCR[4], V_SCR[5], V_SCR[6], V_SCR[7], V_SCR[8]
         for m in range(32):
             self.lds_wait(min(15, 31 - m))
             v = R_K + m
-            e("v_add_u32 v%d, %d, v%d" % (x, 16 * m, vb))
-            e("v_bfe_i32 v%d, v%d, 9, 1" % (sg, x))                      # 0 or ~0: X^N = -1
-            e("v_bfe_u32 v%d, v%d, 9, 1" % (ng, x))                      # 0 or 1 = -sg
-            e("v_xor_b32 v%d, v%d, v%d" % (y, v, sg))
-            e("v_sub_u32 v%d, v%d, v%d" % (ng, ng, V_ACC + m))           # -sg - acc
-            e("v_add3_u32 v%d, v%d, v%d, s%d" % (y, y, ng, S_C2048))      # y = sign * v - acc + 2^11
+            # y = sign * acc[src] - acc + 2^11 = (n[src] ^ sg) - sg + n + 2^11 with sg = ~0 where sign = +1
+            e("v_bfe_i32 v%d, v%d, %d, 1" % (sg, fs, m))
+            e("v_bfe_u32 v%d, v%d, %d, 1" % (c, fs, m))
+            e("v_add3_u32 v%d, v%d, v%d, s%d" % (c, c, V_ACC + m, S_C2048))
+            e("v_xad_u32 v%d, v%d, v%d, v%d" % (y, v, sg, c))
             e("v_lshrrev_b32 v%d, 12, v%d" % (s_, y))
             e("v_lshrrev_b32 v%d, 31, v%d" % (u, y))
-            e("v_add_u32 v%d, v%d, v%d" % (u, s_, u))                    # s + bit 19 of the state
-            e("v_add_u32 v%d, 0x7fdff, v%d" % (w, u))
+            e("v_add3_u32 v%d, v%d, v%d, s%d" % (u, s_, u, S_C511))      # s + bit 19 of the state + 511
+            e("v_add_u32 v%d, 0x7fc00, v%d" % (w, u))
             e("v_bfe_u32 v%d, v%d, 10, 10" % (w, w))
             e("v_add_u32 v%d, 0xfffffe01, v%d" % (w, w))                 # d1
             e("v_cvt_f64_i32 %s, v%d" % (dreg(R_A + 2 * m), w))
-            e("v_add_u32 v%d, 0x1ff, v%d" % (u, u))
             e("v_and_b32 v%d, 0xfffffc00, v%d" % (u, u))
             e("v_sub_u32 v%d, v%d, v%d" % (u, s_, u))                    # d2
             e("v_cvt_f64_i32 %s, v%d" % (dreg(R_B + 2 * m), u))
@@ -595,7 +606,7 @@ class Loop:
                 rr, ri = st.fmac(c, nr, magic), st.fmac(c, ni, magic)
                 st.kill(nr, ni)
             for (val, m) in ((rr, n1), (ri, 16 + n1)):
-                st.e("v_add_u32 v%d, v%d, v%d" % (V_ACC + m, V_ACC + m, val.reg))
+                st.e("v_sub_u32 v%d, v%d, v%d" % (V_ACC + m, V_ACC + m, val.reg))      # the negated accumulator
                 st.e("ds_write_b32 v%d, v%d offset:%d" % (V_ROTWR, V_ACC + m, 64 * m))
             st.kill(rr, ri)
         self.out.extend(st.ins)
@@ -609,6 +620,7 @@ class Loop:
         # constants (known only after the body has been generated)
         import struct
         e("s_mov_b32 s%d, 0x800" % S_C2048)
+        e("s_mov_b32 s%d, 0x1ff" % S_C511)
         for j, val in enumerate(self.consts.vals):
             bits = struct.unpack("<Q", struct.pack("<d", val))[0]
             e("s_mov_b32 s%d, 0x%x" % (const_reg(j), bits & 0xFFFFFFFF))
