@@ -52,9 +52,10 @@ def asm_sequence(v, r, m, acc):
         y = (n_src ^ sg) + c
         s, b19 = y >> np.uint32(12), y >> np.uint32(31)
         u = s + b19 + np.uint32(511)
-        d1 = (((u + np.uint32(511 << 10)) >> np.uint32(10)) & np.uint32(1023)).astype(np.int32) - 511
+        f = ((np.uint32(1023) - u) >> np.uint32(10)) & np.uint32(1023)    # the loop produces -d1 and negates in the products
+        nd1 = np.where(f >> np.uint32(9), f | np.uint32(0xFFFFFC00), f).astype(np.int32)
         d2 = (s - (u & np.uint32(0xFFFFFC00))).astype(np.int32)
-    return d1.astype(np.int64), d2.astype(np.int64), idx
+    return -nd1.astype(np.int64), d2.astype(np.int64), idx
 
 
 def test_asm_sequence():

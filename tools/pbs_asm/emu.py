@@ -243,6 +243,14 @@ class Machine:
                 by = np.stack([(words >> np.uint32(8 * j)) & np.uint32(0xFF) for j in range(4)], axis=-1).astype(np.uint8)
                 self.lds_write(addr, by.reshape(W, L, n))
                 self.lds_queue.append(None)
+            elif op == "ds_write_addtid_b32":
+                off = int(re.search(r"offset:(\d+)", rest).group(1)) if "offset:" in rest else 0
+                assert (self.m0 < 65536).all(), "the M0-relative store takes its base from M0[15:0]"
+                addr = self.m0[:, None] + np.uint32(off) + np.uint32(4) * np.arange(L, dtype=np.uint32)[None, :]
+                words = self.v[int(re.match(r"v(\d+)", a[0]).group(1))]
+                by = np.stack([(words >> np.uint32(8 * j)) & np.uint32(0xFF) for j in range(4)], axis=-1).astype(np.uint8)
+                self.lds_write(addr, by.reshape(W, L, 4))
+                self.lds_queue.append(None)
             elif op == "s_xor_b32":
                 self.sdst(a[0], self.ssrc(a[1]) ^ self.ssrc(a[2]))
             elif op == "global_load_dwordx4":
@@ -304,9 +312,8 @@ def main():
     g, t = lane & 3, lane >> 2
     a_tilde = ((((cts >> 21) + 1) >> 1) & 1023).astype(np.uint32)     # [8][806]
     for w in range(W):
-        wl = w * G.K_WAVE_BYTES
-        M.v[G.V_ROTWR][w] = wl + (g * G.K_ROT_STRIDE + t) * 4
-        M.v[G.V_ROTBASE][w] = wl + g * G.K_ROT_STRIDE * 4
+        wl, al = w * G.K_WAVE_LDS, 8 * G.K_WAVE_LDS + w * G.K_A_BYTES    # exchange / rotation buffer, a_tilde array
+        M.v[G.V_ROTBASE][w] = wl + 4 * g
         M.v[G.V_T][w] = t
         for q in range(4):
             M.v[G.V_TRWR[q]][w] = wl + 8 * (g * G.K_TR_GROUP + (t ^ (2 * q)))
@@ -321,17 +328,17 @@ def main():
             M.v[G.V_ACC + m][w] = np.uint32(0) - np.where(g == 3, np.where((jj >> 9) & 1, 0xE0000000, 0x20000000), 0).astype(np.uint32)
         # accumulator into the rotation buffer, a_tilde into its LDS array
         for m in range(32):
-            addr = M.v[G.V_ROTWR][w] + 64 * m
+            addr = wl + 256 * m + 4 * lane        # buffer word 4 (16 m + t) + g
             val = M.v[G.V_ACC + m][w]
             for bb in range(4):
                 M.lds[addr + bb] = (val >> (8 * bb)) & 0xFF
         at = a_tilde[w].astype(np.uint16)
-        M.lds[wl + G.K_WAVE_LDS: wl + G.K_WAVE_LDS + 2 * at.size] = at.view(np.uint8)
+        M.lds[al: al + 2 * at.size] = at.view(np.uint8)
         kw = ((w >> 1) & 1) * 65536 + (w >> 2) * 4096 + 2 * (w & 1) * 1024
         M.s[G.S_KP][w] = kw
         M.s[G.S_KP + 1][w] = 0
         M.s[G.S_STEPS][w] = steps
-        M.s[G.S_ACUR][w] = wl + G.K_WAVE_LDS + 2
+        M.s[G.S_ACUR][w] = al + 2
         M.s[G.S_A][w] = a_tilde[w, 0]
         M.s[G.S_M0ROW][w] = G.K_RING_OFFSET + 2 * w * 1024
         # chunks 0, 1, 2 of step 0 are already on their way when the loop starts

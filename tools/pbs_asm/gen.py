@@ -20,11 +20,10 @@ import os
 import sys
 
 # ---- geometry shared with pbs_kernel.h (PbsGeom<8,1>, quad lanes, swizzled exchange buffer) ----
-K_ROT_STRIDE = 520
 K_TR_GROUP = 260
 K_WAVE_LDS = 8320
-K_WAVE_BYTES = 8320 + 1664
-K_TW_OFFSET = 8 * K_WAVE_BYTES
+K_A_BYTES = 1664
+K_TW_OFFSET = 8 * (K_WAVE_LDS + K_A_BYTES)   # [8 exchange / rotation buffers][8 a_tilde arrays][twiddles][key ring]
 K_TW_ROW_BYTES = 256       # twiddle table [element][t], 16 bytes each
 K_RING_OFFSET = K_TW_OFFSET + 16 * K_TW_ROW_BYTES
 K_CHUNK_BYTES = 16384
@@ -46,6 +45,7 @@ S_M0ROW = 13    # LDS byte address of this wave's first DMA row in ring slot 0
 S_TMP = 14      # s[14:15] scratch pair (DMA row pointer)
 S_C2048 = 16
 S_C511 = 17
+S_ROTM0 = 96     # LDS byte address of this wave's rotation buffer (for the M0-relative stores)
 S_CONST0 = 18   # fp64 constants from here, in pairs
 
 
@@ -55,7 +55,7 @@ def const_reg(index):
     r = S_CONST0 + 2 * index
     return r + 2 if r >= 32 else r
 
-V_ROTWR, V_ROTBASE, V_T = 1, 2, 3
+V_ROTBASE, V_T = 2, 3          # v2 = rotation buffer + 4 g
 V_TRWR = [4, 5, 6, 7]            # exchange store address for element groups r >> 2
 V_TRRD = [8, 9, 10, 11]          # exchange row-read address for words (w & 3), offset 64 * (w >> 2)
 V_KBASE = 12                     # LDS base + lane * 16: key words are read at v12 + ring offset
@@ -342,11 +342,11 @@ class Loop:
         e("v_bfe_i32 v%d, v%d, 9, 1" % (fs, tmp))
         e("v_xnor_b32 v%d, v%d, v%d" % (fs, fw, fs))                      # bit m set: sign = +1, the negated n[src] enters
         e("v_and_b32 v%d, 0x1ff, v%d" % (tmp, tmp))
-        e("v_lshl_add_u32 v%d, v%d, 2, v%d" % (a0, tmp, V_ROTBASE))
+        e("v_lshl_add_u32 v%d, v%d, 4, v%d" % (a0, tmp, V_ROTBASE))    # buffer word 4 index + g
         for m in range(32):
             e("v_bfe_i32 v%d, v%d, %d, 1" % (tmp, fw, m))
-            e("v_lshl_add_u32 v%d, v%d, 11, v%d" % (tmp, tmp, a0))      # a0 - 2048 once wrapped
-            e("ds_read_b32 v%d, v%d offset:%d" % (R_K + m, tmp, 64 * m))
+            e("v_lshl_add_u32 v%d, v%d, 13, v%d" % (tmp, tmp, a0))      # a0 - 8192 once wrapped
+            e("ds_read_b32 v%d, v%d offset:%d" % (R_K + m, tmp, 256 * m))
         # the m-th read has returned when at most 31 - m younger ones are in flight (the counter saturates at 15)
         sg, c, y, s_, u, w = V_SCR[3], V_SCR[4], V_SCR[5], V_SCR[6], V_SCR[7], V_SCR[8]
         for m in range(32):
@@ -360,9 +360,10 @@ class Loop:
             e("v_lshrrev_b32 v%d, 12, v%d" % (s_, y))
             e("v_lshrrev_b32 v%d, 31, v%d" % (u, y))
             e("v_add3_u32 v%d, v%d, v%d, s%d" % (u, s_, u, S_C511))      # s + bit 19 of the state + 511
-            e("v_add_u32 v%d, 0x7fc00, v%d" % (w, u))
-            e("v_bfe_u32 v%d, v%d, 10, 10" % (w, w))
-            e("v_add_u32 v%d, 0xfffffe01, v%d" % (w, w))                 # d1
+            # -d1: the top digit is the value in [-511, 512] congruent to u >> 10 mod 1024, so its negative is the
+            # sign-extended 10-bit field of (1023 - u) >> 10 = -(u >> 10); array A carries the sign to the products
+            e("v_sub_u32 v%d, 0x3ff, v%d" % (w, u))
+            e("v_bfe_i32 v%d, v%d, 10, 10" % (w, w))
             e("v_cvt_f64_i32 %s, v%d" % (dreg(R_A + 2 * m), w))
             e("v_and_b32 v%d, 0xfffffc00, v%d" % (u, u))
             e("v_sub_u32 v%d, v%d, v%d" % (u, s_, u))                    # d2
@@ -461,6 +462,7 @@ class Loop:
             more = pos + 1 < 16
             opens = more and (pos + 1) % 2 == 0
             f1, f2 = A.val(k2), B.val(k2)
+            f1 = C(-f1.r, -f1.i)                      # array A is the spectrum of the NEGATED level-1 digits
             if opens:
                 self.acquire((pos + 1) // 2)   # place_waits() drains the old chunk's reads before the barrier
             prod = []
@@ -561,7 +563,7 @@ class Loop:
         self.dft16(A, 1, True)
         self.out.extend(self.spread(self.capture(self.tw_mul, A, 0, 8, R_K, 1), self.capture(self.tw_issue, 8, 8, R_T), 0, 32 if "tw_spread" in OPT else 0))
         self.tw_mul(A, 8, 8, R_T, 1)
-        side = self.capture(self.exchange, A) + self.capture(self.tw_issue, 0, 8, R_K)
+        side = self.capture(self.exchange, A)       # twiddles 0-7 stay in R_K for level 2 (nothing else uses it until the key arrives)
         main = self.capture(self.dft16, B, 1, True)
         self.out.extend(self.spread(main, side))
         self.out.extend(self.spread(self.capture(self.tw_mul, B, 0, 8, R_K, 1), self.capture(self.tw_issue, 8, 8, R_T), 0, 32 if "tw_spread" in OPT else 0))
@@ -607,10 +609,15 @@ class Loop:
                 st.kill(nr, ni)
             for (val, m) in ((rr, n1), (ri, 16 + n1)):
                 st.e("v_sub_u32 v%d, v%d, v%d" % (V_ACC + m, V_ACC + m, val.reg))      # the negated accumulator
-                st.e("ds_write_b32 v%d, v%d offset:%d" % (V_ROTWR, V_ACC + m, 64 * m))
+                # buffer word 4 (16 m + t) + g = 64 m + lane: the store needs no address register
+                st.e("ds_write_addtid_b32 v%d offset:%d" % (V_ACC + m, 256 * m))
             st.kill(rr, ri)
         self.out.extend(st.ins)
         assert len(self.pool.free) == 16
+        # M0 is shared with the ring's LDS-DMA (acquire() sets it before each of its loads): point it at the rotation
+        # buffer in front of the first store of the tail
+        k = next(i for i, ln in enumerate(self.out) if ln.startswith("ds_write_addtid_b32"))
+        self.out[k:k] = ["s_mov_b32 m0, s%d" % S_ROTM0, "s_nop 0"]
 
     def build(self):
         e = self.e
@@ -621,6 +628,7 @@ class Loop:
         import struct
         e("s_mov_b32 s%d, 0x800" % S_C2048)
         e("s_mov_b32 s%d, 0x1ff" % S_C511)
+        e("v_readfirstlane_b32 s%d, v%d" % (S_ROTM0, V_ROTBASE))       # lane 0: g = 0, the buffer's first byte
         for j, val in enumerate(self.consts.vals):
             bits = struct.unpack("<Q", struct.pack("<d", val))[0]
             e("s_mov_b32 s%d, 0x%x" % (const_reg(j), bits & 0xFFFFFFFF))
@@ -757,7 +765,7 @@ def main():
     if flags:
         lines = experiment_filter(lines, flags)
     v, s = clobbers(lines)
-    inputs_v = set([V_ROTWR, V_ROTBASE, V_T] + V_TRWR + V_TRRD + [V_KBASE, V_TW, V_LANE16]) | set(range(V_ACC, V_ACC + 32))
+    inputs_v = set([V_ROTBASE, V_T] + V_TRWR + V_TRRD + [V_KBASE, V_TW, V_LANE16]) | set(range(V_ACC, V_ACC + 32))
     inputs_s = set([S_KP, S_KP + 1, S_STEPS, S_ACUR, S_A, S_M0ROW])
     assert 0 not in v and not (set(range(0, 8)) & set(s)), "v0 / s0-s7 belong to the compiler"
     cl = ['"v%d"' % r for r in v if r not in inputs_v] + ['"s%d"' % r for r in s if r not in inputs_s]
