@@ -52,7 +52,7 @@ def measured_traffic():
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 cur = json.load(f)["counters_current_kernels"]
-            c = next(v for k, v in cur.items() if "pbs_asm_kernel<0>" in k or k.startswith("tfa::pbs_kernel<8"))
+            c = next(v for k, v in cur.items() if "pbs_asm_kernel<0, 8>" in k or "pbs_asm_kernel<0>" in k or k.startswith("tfa::pbs_kernel<8"))
             return int((2 * c["FETCH_SIZE@65536"] + c["WRITE_SIZE@65536"]) * 1024), name
         except (OSError, KeyError, ValueError, StopIteration):
             continue

@@ -41,21 +41,27 @@ def gpu_ctx(okeys):
     ctx.close()
 
 
-@pytest.fixture(scope="module", params=[1, 2, 4, 8], ids=lambda v: f"variant{v}")
+@pytest.fixture(scope="module", params=[1, 2, 4, 8, "1c", "2c", "4c", "8c"], ids=lambda v: f"variant{v}")
 def variant_ctx(request, okeys):
-    """Engine context pinned to one bootstrap kernel variant (TFA_PBS_WAVES is read when the context is
-    created): 1 / 2 = one bootstrap per workgroup with one / two workgroups per CU, 4 / 8 = one bootstrap per
-    wave with 4 / 8 waves per workgroup."""
+    """Engine context pinned to one bootstrap kernel variant (the switches are read when the context is created):
+    1 / 2 = one bootstrap per workgroup with one / two workgroups per CU, 4 / 8 = one bootstrap per wave with 4 / 8 waves
+    per workgroup; a trailing "c" selects the compiler-scheduled twin of the hand-scheduled kernel (TFA_PBS_ASM=0,
+    TFA_LAT_ASM=0)."""
     from tfhe_aes_amd import engine as E
-    old = os.environ.get("TFA_PBS_WAVES")
-    os.environ["TFA_PBS_WAVES"] = str(request.param)
+    compiled = str(request.param).endswith("c")
+    env = {"TFA_PBS_WAVES": str(request.param).rstrip("c")}
+    if compiled:
+        env.update(TFA_PBS_ASM="0", TFA_LAT_ASM="0")
+    old = {k: os.environ.get(k) for k in ("TFA_PBS_WAVES", "TFA_PBS_ASM", "TFA_LAT_ASM")}
+    os.environ.update(env)
     try:
         ctx = E.Context(E.default_params(), 0)
     finally:
-        if old is None:
-            del os.environ["TFA_PBS_WAVES"]
-        else:
-            os.environ["TFA_PBS_WAVES"] = old
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     ctx.keys_upload(okeys[2], okeys[3])
     yield ctx
     ctx.close()

@@ -18,7 +18,7 @@ CSRC = os.path.join(ROOT, "tfhe-aes_amd", "csrc")
 
 def _run(script, args=(), env=None):
     e = dict(os.environ)
-    for k in ("PBS_ASM_EXP", "PBS_ASM_OPT", "PBS_ASM_MANUAL_WAITS", "PBS_LAT_PER_CU"):
+    for k in ("PBS_ASM_EXP", "PBS_ASM_OPT", "PBS_ASM_MANUAL_WAITS", "PBS_ASM_WAVES", "PBS_LAT_PER_CU"):
         e.pop(k, None)
     e.update(env or {})
     return subprocess.run([sys.executable, os.path.join(TOOLS, script), *args], env=e, capture_output=True, text=True, timeout=600)
@@ -26,6 +26,7 @@ def _run(script, args=(), env=None):
 
 @pytest.mark.parametrize("script,inc,env", [
     ("gen.py", "pbs_asm_loop.inc", {}),
+    ("gen.py", "pbs_asm_loop4.inc", {"PBS_ASM_WAVES": "4"}),
     ("lat_gen.py", "pbs_lat_asm_loop.inc", {}),
     ("lat_gen.py", "pbs_lat_asm_loop2.inc", {"PBS_LAT_PER_CU": "2"}),
 ])
@@ -38,6 +39,7 @@ def test_committed_loop_is_generator_output(tmp_path, script, inc, env):
 
 @pytest.mark.parametrize("script,env", [
     ("emu.py", {}),
+    ("emu.py", {"PBS_ASM_WAVES": "4"}),
     ("lat_emu.py", {}),
     ("lat_emu.py", {"PBS_LAT_PER_CU": "2"}),
 ])

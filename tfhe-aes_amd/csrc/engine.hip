@@ -241,8 +241,9 @@ extern "C" int tfa_ctx_create(const tfa_params *p, int hip_device, tfa_ctx **out
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bsk_convert_lat_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLatConvertLdsBytes));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, PbsGeom<4>::kLdsBytes));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, PbsGeom<8>::kLdsBytes));
-    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_asm_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, PbsGeom<8>::kLdsBytes));
-    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_asm_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, PbsGeom<8>::kLdsBytes));
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_asm_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, AsmGeom<8>::kLdsBytes));
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_asm_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, AsmGeom<8>::kLdsBytes));
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(pbs_asm_kernel<0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, AsmGeom<4>::kLdsBytes));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(bsk_convert_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kConvertLdsBytes));
     return noalloc_setup(ctx);
 }
@@ -442,13 +443,16 @@ extern "C" int tfa_pool_device_ptr(tfa_ctx *ctx, void **dptr, uint32_t *stride_w
 static void launch_variant(tfa_ctx *ctx, int variant, const uint32_t *in_base, uint32_t in_stride, const PbsJob *jobs, uint32_t count, uint32_t steps,
                            uint32_t *big, uint32_t *acc, bool calibration = false) {
     if (variant == 8 && ctx->pbs_asm && calibration)
-        hipLaunchKernelGGL(pbs_asm_kernel<1>, dim3((count + 7) / 8), dim3(512), PbsGeom<8>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
+        hipLaunchKernelGGL(pbs_asm_kernel<1>, dim3((count + 7) / 8), dim3(512), AsmGeom<8>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
                            ctx->d_bsk_f, ctx->d_tw, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
     else if (variant == 8 && ctx->pbs_asm)
-        hipLaunchKernelGGL(pbs_asm_kernel<0>, dim3((count + 7) / 8), dim3(512), PbsGeom<8>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
+        hipLaunchKernelGGL(pbs_asm_kernel<0>, dim3((count + 7) / 8), dim3(512), AsmGeom<8>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
                            ctx->d_bsk_f, ctx->d_tw, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
     else if (variant == 8)
         hipLaunchKernelGGL(pbs_kernel<8>, dim3((count + 7) / 8), dim3(512), PbsGeom<8>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
+                           ctx->d_bsk_f, ctx->d_tw, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
+    else if (variant == 4 && ctx->pbs_asm)
+        hipLaunchKernelGGL((pbs_asm_kernel<0, 4>), dim3((count + 3) / 4), dim3(256), AsmGeom<4>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
                            ctx->d_bsk_f, ctx->d_tw, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
     else if (variant == 4)
         hipLaunchKernelGGL(pbs_kernel<4>, dim3((count + 3) / 4), dim3(256), PbsGeom<4>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,

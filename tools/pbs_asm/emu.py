@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 import gen as G  # noqa: E402
 
-W, L = 8, 64
+W, L = G.WAVES, 64
 
 
 class Machine:
@@ -302,7 +302,7 @@ def main():
     from oracle.pyoracle import Oracle
     o = Oracle()
     lwe_sk, glwe_sk, bsk, ksk = o.keygen(0x5446484541455321)
-    bits = np.array([0, 1, 1, 0, 1, 0, 0, 1], np.uint8)
+    bits = np.array([0, 1, 1, 0, 1, 0, 0, 1], np.uint8)[:W]
     cts = o.encrypt_bits(lwe_sk, 77, 0, bits)
     cts[2, 1] = 0      # a mask word that modulus-switches to zero
     n = 805
@@ -312,7 +312,7 @@ def main():
     g, t = lane & 3, lane >> 2
     a_tilde = ((((cts >> 21) + 1) >> 1) & 1023).astype(np.uint32)     # [8][806]
     for w in range(W):
-        wl, al = w * G.K_WAVE_LDS, 8 * G.K_WAVE_LDS + w * G.K_A_BYTES    # exchange / rotation buffer, a_tilde array
+        wl, al = w * G.K_WAVE_LDS, W * G.K_WAVE_LDS + w * G.K_A_BYTES    # exchange / rotation buffer, a_tilde array
         M.v[G.V_ROTBASE][w] = wl + 4 * g
         M.v[G.V_T][w] = t
         for q in range(4):
@@ -334,17 +334,19 @@ def main():
                 M.lds[addr + bb] = (val >> (8 * bb)) & 0xFF
         at = a_tilde[w].astype(np.uint16)
         M.lds[al: al + 2 * at.size] = at.view(np.uint8)
-        kw = ((w >> 1) & 1) * 65536 + (w >> 2) * 4096 + 2 * (w & 1) * 1024
+        rpw = G.ROWS_PER_WAVE
+        r0 = rpw * w                           # this wave's first DMA row of a chunk: row = (position >> 1) << 3 | level << 2 | column
+        kw = ((r0 >> 2) & 1) * 65536 + (r0 >> 3) * 4096 + (r0 & 3) * 1024
         M.s[G.S_KP][w] = kw
         M.s[G.S_KP + 1][w] = 0
         M.s[G.S_STEPS][w] = steps
         M.s[G.S_ACUR][w] = al + 2
         M.s[G.S_A][w] = a_tilde[w, 0]
-        M.s[G.S_M0ROW][w] = G.K_RING_OFFSET + 2 * w * 1024
+        M.s[G.S_M0ROW][w] = G.K_RING_OFFSET + r0 * 1024
         # chunks 0, 1, 2 of step 0 are already on their way when the loop starts
         for ch in range(3):
-            for row in (2 * w, 2 * w + 1):
-                src = kw + ch * 8192 + (row - 2 * w) * 1024
+            for row in range(r0, r0 + rpw):
+                src = kw + ch * 8192 + (row - r0) * 1024
                 dst = G.K_RING_OFFSET + ch * G.K_CHUNK_BYTES + row * 1024
                 M.lds[dst:dst + 1024] = key[src:src + 1024]
     twt = np.zeros((16, 16), np.complex128)

@@ -23,7 +23,10 @@ import sys
 K_TR_GROUP = 260
 K_WAVE_LDS = 8320
 K_A_BYTES = 1664
-K_TW_OFFSET = 8 * (K_WAVE_LDS + K_A_BYTES)   # [8 exchange / rotation buffers][8 a_tilde arrays][twiddles][key ring]
+WAVES = int(os.environ.get("PBS_ASM_WAVES", "8"))     # bootstraps per workgroup: 8 (two waves per SIMD) or 4 (one per SIMD, for 1024-wide stages)
+assert WAVES in (4, 8)
+ROWS_PER_WAVE = 16 // WAVES                          # LDS-DMA rows of a key chunk each wave fetches
+K_TW_OFFSET = WAVES * (K_WAVE_LDS + K_A_BYTES)   # [exchange / rotation buffers][a_tilde arrays][twiddles][key ring]
 K_TW_ROW_BYTES = 256       # twiddle table [element][t], 16 bytes each
 K_RING_OFFSET = K_TW_OFFSET + 16 * K_TW_ROW_BYTES
 K_CHUNK_BYTES = 16384
@@ -424,21 +427,20 @@ class Loop:
         """chunk q of the current step: own DMA rows landed, barrier, refill the slot freed by the previous chunk with
         chunk q + 3 (the key buffer is padded, so the prefetch needs no end-of-key test), key read address of chunk q"""
         e = self.e
-        e("s_waitcnt vmcnt(4)")
+        e("s_waitcnt vmcnt(%d)" % (2 * ROWS_PER_WAVE))       # own rows of chunk q: at most the two younger chunks' rows stay in flight
         e("s_barrier")
         qq = q + 3
         off = qq * 8192 if qq < 8 else STEP_KEY_BYTES + (qq - 8) * 8192
         slot = qq % 4
-        e("s_add_u32 s%d, s%d, 0x%x" % (S_TMP, S_KP, off))
-        e("s_addc_u32 s%d, s%d, 0" % (S_TMP + 1, S_KP + 1))
-        e("s_add_u32 m0, s%d, 0x%x" % (S_M0ROW, slot * K_CHUNK_BYTES))
-        e("s_nop 0")
-        e("global_load_lds_dwordx4 v%d, s[%d:%d]" % (V_LANE16, S_TMP, S_TMP + 1))
-        e("s_add_u32 s%d, s%d, 0x400" % (S_TMP, S_TMP))
-        e("s_addc_u32 s%d, s%d, 0" % (S_TMP + 1, S_TMP + 1))
-        e("s_add_u32 m0, s%d, 0x%x" % (S_M0ROW, slot * K_CHUNK_BYTES + 1024))
-        e("s_nop 0")
-        e("global_load_lds_dwordx4 v%d, s[%d:%d]" % (V_LANE16, S_TMP, S_TMP + 1))
+        for j in range(ROWS_PER_WAVE):
+            if j == 0:
+                e("s_add_u32 s%d, s%d, 0x%x" % (S_TMP, S_KP, off))
+            else:
+                e("s_add_u32 s%d, s%d, 0x400" % (S_TMP, S_TMP))
+            e("s_addc_u32 s%d, s%d, 0" % (S_TMP + 1, S_KP + 1 if j == 0 else S_TMP + 1))
+            e("s_add_u32 m0, s%d, 0x%x" % (S_M0ROW, slot * K_CHUNK_BYTES + 1024 * j))
+            e("s_nop 0")
+            e("global_load_lds_dwordx4 v%d, s[%d:%d]" % (V_LANE16, S_TMP, S_TMP + 1))
         e("v_add_u32 v%d, 0x%x, v%d" % (V_KADDR, K_RING_OFFSET + (q % 4) * K_CHUNK_BYTES, V_KBASE))
 
     def key_issue(self, pos, pair):
@@ -752,7 +754,7 @@ def experiment_filter(lines, flags):
             continue
         if "nobar" in flags and op == "s_barrier":
             continue
-        if "nodma" in flags and (op.startswith("global_load_lds") or (op == "s_waitcnt" and ln.strip() == "s_waitcnt vmcnt(4)")):
+        if "nodma" in flags and (op.startswith("global_load_lds") or (op == "s_waitcnt" and ln.strip() == "s_waitcnt vmcnt(%d)" % (2 * ROWS_PER_WAVE))):
             continue
         out.append(ln)
     return out
@@ -772,11 +774,11 @@ def main():
     out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tfhe-aes_amd", "csrc", "pbs_asm_loop.inc")
     with open(out_path, "w") as f:
         f.write("// GENERATED by tools/pbs_asm/gen.py - do not edit.  %d instructions per blind-rotation step.\n" % len([x for x in lines if not x.endswith(":")]))
-        f.write("#define TFA_PBS_ASM_BODY \\\n")
+        f.write("#define TFA_PBS_ASM%s_BODY \\\n" % ("" if WAVES == 8 else "4"))
         for ln in lines:
             f.write('    "%s\\n\\t" \\\n' % ln)
         f.write('    ""\n')
-        f.write("#define TFA_PBS_ASM_CLOBBERS %s\n" % ", ".join(cl + ['"memory"', '"scc"', '"vcc"']))
+        f.write("#define TFA_PBS_ASM%s_CLOBBERS %s\n" % ("" if WAVES == 8 else "4", ", ".join(cl + ['"memory"', '"scc"', '"vcc"'])))
     stats = {}
     for ln in lines:
         op = ln.split()[0]

@@ -13,7 +13,7 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
         with open(f) as fh:
             for row in csv.DictReader(fh):
                 k = row["Kernel_Name"].split("(")[0]
-                if ("pbs_" not in k and "keyswitch" not in k) or "pbs_asm_kernel<1>" in k:   # <1>: the calibration's launches
+                if ("pbs_" not in k and "keyswitch" not in k) or "pbs_asm_kernel<1" in k:   # <1, ...>: the calibration's launches
                     continue
                 acc.setdefault((k, row["Counter_Name"]), []).append((int(row["Grid_Size"]), float(row["Counter_Value"])))
         for (k, c), v in acc.items():
@@ -57,7 +57,7 @@ res = {"note": "rocprofv3 --pmc, separate passes (tools/profile_round.sh), reduc
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "pbs_asm"))
 for k, c in out.items():
     try:
-        if "pbs_asm_kernel<0>" in k:
+        if "pbs_asm_kernel<0, 8>" in k or "pbs_asm_kernel<0>" in k:
             import gen
             res["derived_pbs_asm_kernel"] = derived(c, 1)
             res["derived_pbs_asm_kernel"]["fp64_instructions_per_wave_step"] = fp64_mix(gen.Loop().build())
