@@ -38,8 +38,9 @@ def load_constants(M):
         M.v[LG.V_ROTWR][w] = wl + 4 * lane
         M.v[LG.V_ROTBASE][w] = wl
         M.v[LG.V_L][w] = lane
-        for s in range(4):
-            M.v[LG.V_POS[s]][w] = wl + 16 * np.array([LG.lat_pos(s, int(l), 0) for l in lane])
+        for e in range(3):
+            M.v[LG.V_PA[e]][w] = wl + 16 * np.array([LG.exch_pos(e, e, int(l), 0) for l in lane])
+            M.v[LG.V_PB[e]][w] = wl + 16 * np.array([LG.exch_pos(e, e + 1, int(l), 0) for l in lane])
         M.v[LG.V_SPECWR][w] = LG.K_RED_OFFSET + 16 * (w * 8 * 64 + lane)
         for k in range(3):
             M.v[LG.V_SPECRD[k]][w] = LG.K_RED_OFFSET + 16 * ((((w + k + 1) & 3) * 8) * 64 + lane)

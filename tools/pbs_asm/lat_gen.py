@@ -56,7 +56,8 @@ S_TW = 36                                 # s[36:37] twiddle table in global mem
 S_KEY = 20                                # s[20 + 2 j : 21 + 2 j], j = lv * 4 + k
 
 V_ROTWR, V_ROTBASE, V_L = 1, 2, 3
-V_POS = [4, 5, 6, 7]
+V_PA = [4, 5, 6]                          # lane's position in hand-over e's layout at stage e
+V_PB = [7, 28, 29]                        # ... at stage e + 1
 V_SPECWR, V_SPECRD, V_KOFF, V_TWADDR = 8, [9, 10, 11], 12, 13
 V_SPECWR_CUR, V_SPECRD_CUR = 14, [15, 16, 17]
 V_AREAD = 18
@@ -70,15 +71,24 @@ R_T = 116
 R_KEY = 128
 
 
-def lat_pos(s, L, slot):
-    quarter = 64 >> (2 * s)
-    p0 = (L // quarter) * (4 * quarter) + (L & (quarter - 1))
-    return p0 + (p0 >> 2) + slot * (5 * quarter // 4 if s < 3 else 1)
+# Hand-over buffers.  A lane holds, at stage s, the four elements whose base-4 index digit (3 - s) runs over the slots; its
+# other three digits come from the lane number.  Every hand-over e (between stages e and e + 1, in either direction) has
+# its own layout, a stride per digit in 16-byte units, chosen so that the ds_write_b128 of both stages (groups of 8
+# contiguous lanes, 32 banks) and the ds_read_b128 of both stages (the instruction's four 16-lane groups, 64 banks) are all free of
+# bank conflicts; no single layout does that for all four stages.
+EXCH_STRIDES = [(64, 16, 4, 1), (16, 68, 4, 1), (80, 4, 17, 1)]      # (digit 3, 2, 1, 0)
 
 
-def slot_stride_bytes(s):
-    quarter = 64 >> (2 * s)
-    return 16 * (5 * quarter // 4 if s < 3 else 1)
+def exch_pos(e, s, L, slot):
+    """16-byte position, in hand-over e's layout, of slot `slot` of lane L at stage s (s = e or e + 1)"""
+    assert s in (e, e + 1)
+    lane_digits = [(L >> 4) & 3, (L >> 2) & 3, L & 3]
+    lane_digits.insert(s, slot)                                      # digits (3, 2, 1, 0); stage s owns digit 3 - s
+    return sum(d * st for d, st in zip(lane_digits, EXCH_STRIDES[e]))
+
+
+def slot_stride_bytes(e, s):
+    return 16 * EXCH_STRIDES[e][s]
 
 
 class Quad:
@@ -127,13 +137,15 @@ class Lat:
         self.out.extend(st.ins)
 
     # ---- hand-over between stages ----
-    def ho_write(self, zbase, lv, s):
+    def ho_write(self, zbase, lv, s, e):
+        reg = V_PA[e] if s == e else V_PB[e]
         for r in range(4):
-            self.e("ds_write_b128 v%d, %s offset:%d" % (V_POS[s], qreg(zbase + 4 * r), lv * K_FFT_BYTES + r * slot_stride_bytes(s)))
+            self.e("ds_write_b128 v%d, %s offset:%d" % (reg, qreg(zbase + 4 * r), lv * K_FFT_BYTES + r * slot_stride_bytes(e, s)))
 
-    def ho_read(self, zbase, lv, s):
+    def ho_read(self, zbase, lv, s, e):
+        reg = V_PA[e] if s == e else V_PB[e]
         for q in range(4):
-            self.e("ds_read_b128 %s, v%d offset:%d" % (qreg(zbase + 4 * q), V_POS[s], lv * K_FFT_BYTES + q * slot_stride_bytes(s)))
+            self.e("ds_read_b128 %s, v%d offset:%d" % (qreg(zbase + 4 * q), reg, lv * K_FFT_BYTES + q * slot_stride_bytes(e, s)))
 
     def tw_read(self, s, regs):
         """the three twiddles of stage s (1 or 2) into three quads"""
@@ -195,8 +207,8 @@ class Lat:
                     self.cmul(z + 4 * (r + 1), tw, 1, scr)
                 if s == 1 and lv == 1:
                     self.tw_read(2, twq)                   # stage 1 has used its twiddles: the registers take stage 2's
-                self.ho_write(z, lv, s)
-                self.ho_read(z, lv, s + 1)
+                self.ho_write(z, lv, s, s)
+                self.ho_read(z, lv, s + 1, s)
 
     def publish_and_own_term(self):
         e = self.e
@@ -268,8 +280,8 @@ class Lat:
                     self.cmul(z + 4 * (r + 1), tw, -1, scr)
             self.dft4(z, -1, pool)
             if s > 0:
-                self.ho_write(z, 0, s)
-                self.ho_read(z, 0, s - 1)
+                self.ho_write(z, 0, s, s - 1)
+                self.ho_read(z, 0, s - 1, s - 1)
         for q in range(4):
             self.cmul(z + 4 * q, R_TWIST + 4 * q, -1, scr)
 
@@ -380,7 +392,7 @@ def experiment_filter(lines, flags):
             continue
         if "nowait" in flags and ln.startswith("s_waitcnt lgkmcnt("):
             continue
-        if "noho" in flags and op in ("ds_write_b128", "ds_read_b128") and any(", v%d " % r in ln + " " or ln.startswith("ds_write_b128 v%d," % r) for r in V_POS):
+        if "noho" in flags and op in ("ds_write_b128", "ds_read_b128") and any(", v%d " % r in ln + " " or ln.startswith("ds_write_b128 v%d," % r) for r in V_PA + V_PB):
             continue
         if "nospec" in flags and op == "ds_read_b128" and any(", v%d " % r in ln + " " for r in V_SPECRD_CUR):
             continue
@@ -395,7 +407,7 @@ def main():
     if flags:
         lines = experiment_filter(lines, flags)
     v, s = G.clobbers(lines)
-    inputs_v = set([V_ROTWR, V_ROTBASE, V_L] + V_POS + [V_SPECWR] + V_SPECRD + [V_KOFF, V_TWADDR]) | set(range(V_ACC, V_ACC + 8))
+    inputs_v = set([V_ROTWR, V_ROTBASE, V_L] + V_PA + V_PB + [V_SPECWR] + V_SPECRD + [V_KOFF, V_TWADDR]) | set(range(V_ACC, V_ACC + 8))
     inputs_s = set([S_STEPS, S_ACUR, S_A, S_PAR, S_TW, S_TW + 1]) | set(range(S_KEY, S_KEY + 16))
     assert 0 not in v and not (set(range(0, 8)) & set(s)), "v0 / s0-s7 belong to the compiler"
     cl = ['"v%d"' % r for r in v if r not in inputs_v] + ['"s%d"' % r for r in s if r not in inputs_s]
