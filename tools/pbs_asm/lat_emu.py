@@ -35,7 +35,6 @@ def load_constants(M):
     lane = np.arange(L)
     for w in range(W):
         wl = w * LG.K_WAVE_BYTES
-        M.v[LG.V_ROTWR][w] = wl + 4 * lane
         M.v[LG.V_ROTBASE][w] = wl
         M.v[LG.V_L][w] = lane
         for e in range(3):
@@ -131,9 +130,10 @@ def main():
     for w in range(W):
         for m in range(8):
             jj = 64 * m + lane + b_tilde
-            acc = np.where(w == 3, np.where((jj >> 9) & 1, 0xE0000000, 0x20000000), 0).astype(np.uint32)
+            # the loop keeps the accumulator negated, in its registers and in the rotation buffer
+            acc = np.uint32(0) - np.where(w == 3, np.where((jj >> 9) & 1, 0xE0000000, 0x20000000), 0).astype(np.uint32)
             M.v[LG.V_ACC + m][w] = acc
-            addr = M.v[LG.V_ROTWR][w] + 256 * m
+            addr = w * LG.K_WAVE_BYTES + 4 * lane + 256 * m
             for bb in range(4):
                 M.lds[addr + bb] = (acc >> (8 * bb)) & 0xFF
         M.s[LG.S_STEPS][w] = steps
@@ -154,7 +154,7 @@ def main():
     got = np.zeros((4, 512), np.uint32)
     for w in range(W):
         for m in range(8):
-            got[w, 64 * m + lane] = M.v[LG.V_ACC + m][w]
+            got[w, 64 * m + lane] = np.uint32(0) - M.v[LG.V_ACC + m][w]
     bad = int((got != ref).sum())
     if bad:
         d = (got.astype(np.int64) - ref.astype(np.int64) + 2**31) % 2**32 - 2**31

@@ -52,10 +52,11 @@ MAGIC = 6755399441055744.0
 
 S_STEPS, S_ACUR, S_A, S_PAR, S_TMP = 10, 11, 12, 13, 14
 S_C2048 = 16
+S_C511 = 17
 S_TW = 36                                 # s[36:37] twiddle table in global memory (prologue only)
 S_KEY = 20                                # s[20 + 2 j : 21 + 2 j], j = lv * 4 + k
 
-V_ROTWR, V_ROTBASE, V_L = 1, 2, 3
+V_ROTBASE, V_L = 2, 3
 V_PA = [4, 5, 6]                          # lane's position in hand-over e's layout at stage e
 V_PB = [7, 28, 29]                        # ... at stage e + 1
 V_SPECWR, V_SPECRD, V_KOFF, V_TWADDR = 8, [9, 10, 11], 12, 13
@@ -154,35 +155,41 @@ class Lat:
 
     # ---- the step ----
     def rotate_decompose(self):
+        """d = acc * X^a - acc for this wave's polynomial (lane L: coefficients L + 64 m), both digits as doubles.  Same
+        scheme as the wide loop (gen.py: rotate_decompose): registers and rotation buffer hold the negated accumulator, one
+        mask per lane and step marks the coefficients whose index wrapped past 511 (read address - 2048 bytes, sign
+        flipped), and the top digit is produced negated (mac_block flips the sign of the level-1 spectra)."""
         e = self.e
-        vb, x, ad = V_SCR[0], V_SCR[1], V_SCR[2]
+        fw, fs, a0, tmp = V_SCR[0], V_SCR[1], V_SCR[2], V_SCR[3]
         rk = [R_T + m for m in range(8)]
-        e("v_subrev_u32 v%d, s%d, v%d" % (vb, S_A, V_L))                # L - a
+        e("v_subrev_u32 v%d, s%d, v%d" % (tmp, S_A, V_L))                # r = L - a
+        e("v_not_b32 v%d, v%d" % (fw, tmp))
+        e("v_bfe_u32 v%d, v%d, 6, 3" % (fw, fw))                          # (511 - (r & 511)) >> 6
+        e("v_lshlrev_b32 v%d, v%d, -2" % (fw, fw))                        # bit m set: index wrapped
+        e("v_bfe_i32 v%d, v%d, 9, 1" % (fs, tmp))
+        e("v_xnor_b32 v%d, v%d, v%d" % (fs, fw, fs))                      # bit m set: sign = +1, the negated n[src] enters
+        e("v_and_b32 v%d, 0x1ff, v%d" % (tmp, tmp))
+        e("v_lshl_add_u32 v%d, v%d, 2, v%d" % (a0, tmp, V_ROTBASE))
         for m in range(8):
-            e("v_add_u32 v%d, %d, v%d" % (x, 64 * m, vb))
-            e("v_and_b32 v%d, 0x1ff, v%d" % (ad, x))
-            e("v_lshl_add_u32 v%d, v%d, 2, v%d" % (ad, ad, V_ROTBASE))
-            e("ds_read_b32 v%d, v%d" % (rk[m], ad))
-        sg, ng, y, s_, u, w = V_SCR[3], V_SCR[4], V_SCR[5], V_SCR[6], V_SCR[7], V_SCR[8]
+            e("v_bfe_i32 v%d, v%d, %d, 1" % (tmp, fw, m))
+            e("v_lshl_add_u32 v%d, v%d, 11, v%d" % (tmp, tmp, a0))
+            e("ds_read_b32 v%d, v%d offset:%d" % (rk[m], tmp, 256 * m))
+        sg, c, y, s_, u, w = V_SCR[3], V_SCR[4], V_SCR[5], V_SCR[6], V_SCR[7], V_SCR[8]
         for m in range(8):
             v = rk[m]
             q, part = m & 3, 0 if m < 4 else 2
-            e("v_add_u32 v%d, %d, v%d" % (x, 64 * m, vb))
-            e("v_bfe_i32 v%d, v%d, 9, 1" % (sg, x))
-            e("v_bfe_u32 v%d, v%d, 9, 1" % (ng, x))
-            e("v_xor_b32 v%d, v%d, v%d" % (y, v, sg))
-            e("v_sub_u32 v%d, v%d, v%d" % (ng, ng, V_ACC + m))
-            e("v_add3_u32 v%d, v%d, v%d, s%d" % (y, y, ng, S_C2048))
+            e("v_bfe_i32 v%d, v%d, %d, 1" % (sg, fs, m))
+            e("v_bfe_u32 v%d, v%d, %d, 1" % (c, fs, m))
+            e("v_add3_u32 v%d, v%d, v%d, s%d" % (c, c, V_ACC + m, S_C2048))
+            e("v_xad_u32 v%d, v%d, v%d, v%d" % (y, v, sg, c))
             e("v_lshrrev_b32 v%d, 12, v%d" % (s_, y))
             e("v_lshrrev_b32 v%d, 31, v%d" % (u, y))
-            e("v_add_u32 v%d, v%d, v%d" % (u, s_, u))
-            e("v_add_u32 v%d, 0x7fdff, v%d" % (w, u))
-            e("v_bfe_u32 v%d, v%d, 10, 10" % (w, w))
-            e("v_add_u32 v%d, 0xfffffe01, v%d" % (w, w))
+            e("v_add3_u32 v%d, v%d, v%d, s%d" % (u, s_, u, S_C511))
+            e("v_sub_u32 v%d, 0x3ff, v%d" % (w, u))
+            e("v_bfe_i32 v%d, v%d, 10, 10" % (w, w))                      # -d1
             e("v_cvt_f64_i32 %s, v%d" % (dreg(R_Z[0] + 4 * q + part), w))
-            e("v_add_u32 v%d, 0x1ff, v%d" % (u, u))
             e("v_and_b32 v%d, 0xfffffc00, v%d" % (u, u))
-            e("v_sub_u32 v%d, v%d, v%d" % (u, s_, u))
+            e("v_sub_u32 v%d, v%d, v%d" % (u, s_, u))                    # d2
             e("v_cvt_f64_i32 %s, v%d" % (dreg(R_Z[1] + 4 * q + part), u))
 
     def forward(self):
@@ -220,22 +227,24 @@ class Lat:
         self.mac_block(R_Z[0], 0, 0, first=True)
 
     def mac_block(self, f, lv, k, first):
-        """out[q] += f[q] * key[lv][k][q] for the four q: eight independent chains, two rounds"""
+        """out[q] += f[q] * key[lv][k][q] for the four q: eight independent chains, two rounds.  The level-1 spectra (lv = 0)
+        are those of the negated digits: their sign is flipped here."""
         e = self.e
+        p, n = ("-", "") if lv == 0 else ("", "-")
         for q in range(4):
             orr, oi = dreg(R_OUT + 4 * q), dreg(R_OUT + 4 * q + 2)
             fx, key = dreg(f + 4 * q), R_KEY + ((lv * 4 + k) * 4 + q) * 4
             if first:
-                e("v_mul_f64 %s, %s, %s" % (orr, fx, dreg(key)))
-                e("v_mul_f64 %s, %s, %s" % (oi, fx, dreg(key + 2)))
+                e("v_mul_f64 %s, %s%s, %s" % (orr, p, fx, dreg(key)))
+                e("v_mul_f64 %s, %s%s, %s" % (oi, p, fx, dreg(key + 2)))
             else:
-                e("v_fma_f64 %s, %s, %s, %s" % (orr, fx, dreg(key), orr))
-                e("v_fma_f64 %s, %s, %s, %s" % (oi, fx, dreg(key + 2), oi))
+                e("v_fma_f64 %s, %s%s, %s, %s" % (orr, p, fx, dreg(key), orr))
+                e("v_fma_f64 %s, %s%s, %s, %s" % (oi, p, fx, dreg(key + 2), oi))
         for q in range(4):
             orr, oi = dreg(R_OUT + 4 * q), dreg(R_OUT + 4 * q + 2)
             fy, key = dreg(f + 4 * q + 2), R_KEY + ((lv * 4 + k) * 4 + q) * 4
-            e("v_fma_f64 %s, -%s, %s, %s" % (orr, fy, dreg(key + 2), orr))
-            e("v_fma_f64 %s, %s, %s, %s" % (oi, fy, dreg(key), oi))
+            e("v_fma_f64 %s, %s%s, %s, %s" % (orr, n, fy, dreg(key + 2), orr))
+            e("v_fma_f64 %s, %s%s, %s, %s" % (oi, p, fy, dreg(key), oi))
 
     def spec_read(self, lv, k):
         for q in range(4):
@@ -291,8 +300,8 @@ class Lat:
         for q in range(4):
             for part, m in ((0, q), (2, q + 4)):
                 e("v_add_f64 %s, %s, %s" % (dreg(t), dreg(R_OUT + 4 * q + part), dreg(V_MAGIC)))
-                e("v_add_u32 v%d, v%d, v%d" % (V_ACC + m, V_ACC + m, t))
-                e("ds_write_b32 v%d, v%d offset:%d" % (V_ROTWR, V_ACC + m, 256 * m))
+                e("v_sub_u32 v%d, v%d, v%d" % (V_ACC + m, V_ACC + m, t))              # the negated accumulator
+                e("ds_write_addtid_b32 v%d offset:%d" % (V_ACC + m, 256 * m))            # M0 = this wave's rotation buffer
                 t += 2
 
     def step(self):
@@ -329,6 +338,9 @@ class Lat:
         body.step()
         mbits = struct.unpack("<Q", struct.pack("<d", MAGIC))[0]
         e("s_mov_b32 s%d, 0x800" % S_C2048)
+        e("s_mov_b32 s%d, 0x1ff" % S_C511)
+        e("v_readfirstlane_b32 s%d, v%d" % (S_TMP, V_ROTBASE))         # nothing else in this loop uses M0
+        e("s_mov_b32 m0, s%d" % S_TMP)
         e("v_mov_b32 v%d, 0x%x" % (V_MAGIC, mbits & 0xFFFFFFFF))
         e("v_mov_b32 v%d, 0x%x" % (V_MAGIC + 1, mbits >> 32))
         assert not self.consts.vals, "this loop folds no scalar constants (all its factors are per-lane twiddles)"
@@ -407,7 +419,7 @@ def main():
     if flags:
         lines = experiment_filter(lines, flags)
     v, s = G.clobbers(lines)
-    inputs_v = set([V_ROTWR, V_ROTBASE, V_L] + V_PA + V_PB + [V_SPECWR] + V_SPECRD + [V_KOFF, V_TWADDR]) | set(range(V_ACC, V_ACC + 8))
+    inputs_v = set([V_ROTBASE, V_L] + V_PA + V_PB + [V_SPECWR] + V_SPECRD + [V_KOFF, V_TWADDR]) | set(range(V_ACC, V_ACC + 8))
     inputs_s = set([S_STEPS, S_ACUR, S_A, S_PAR, S_TW, S_TW + 1]) | set(range(S_KEY, S_KEY + 16))
     assert 0 not in v and not (set(range(0, 8)) & set(s)), "v0 / s0-s7 belong to the compiler"
     cl = ['"v%d"' % r for r in v if r not in inputs_v] + ['"s%d"' % r for r in s if r not in inputs_s]
