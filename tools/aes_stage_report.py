@@ -8,8 +8,7 @@ def width(r):
     name, grid, wg = r["Kernel_Name"], int(r["Grid_Size_X"]) if "Grid_Size_X" in r else int(r["Grid_Size"]), int(r["Workgroup_Size_X"]) if "Workgroup_Size_X" in r else int(r["Workgroup_Size"])
     wgs = grid // wg
     if "pbs_lat" in name: return wgs, "lat"
-    if "pbs_asm" in name or "pbs_kernel<8" in name: return wgs * 8, "8w"
-    if "pbs_kernel<4" in name: return wgs * 4, "4w"
+    if "pbs_asm" in name or "pbs_kernel<" in name: return wgs * (wg // 64), "%dw" % (wg // 64)   # one bootstrap per wave
     return None, None
 # the timed block starts after the warm-up SubBytes: take the last 117 stages = everything after the 7th keyswitch
 ks_idx = [i for i, r in enumerate(rows) if "keyswitch" in r["Kernel_Name"] and "init" not in r["Kernel_Name"]]
