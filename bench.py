@@ -59,6 +59,20 @@ def measured_traffic():
     return None, None
 
 
+def measured_issue_profile():
+    """Ratios of the dominant kernel from the same committed PMC passes (profiles/r2_pmc_summary.json, derived by
+    tools/pmc_summary.py): share of wave cycles spent waiting on LDS instructions and issuing, instructions per wave and
+    blind-rotation step, and the FMA share of the loop's fp64 instructions.  None when the file is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", PMC_SUMMARIES[0])) as f:
+            d = json.load(f)["derived_pbs_asm_kernel"]
+        return {"sq_wait_inst_lds_per_wave_cycle": d["SQ_WAIT_INST_LDS/SQ_WAVE_CYCLES"], "sq_active_inst_any_per_wave_cycle": d["SQ_ACTIVE_INST_ANY/SQ_WAVE_CYCLES"],
+                "valu_instructions_per_wave_step": d["valu_instructions_per_wave_step"], "lds_instructions_per_wave_step": d["lds_instructions_per_wave_step"],
+                "fp64_fma_share": d["fp64_instructions_per_wave_step"]["fma_share"], "source": "profiles/" + PMC_SUMMARIES[0]}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(p, lwe_sk, bsk, ksk, budget_s=20.0):
     from oracle.pyoracle import NAND, XOR, Oracle
     o = Oracle()
@@ -421,7 +435,7 @@ def main():
                          "achieved": round(achieved, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP64_PEAK_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": f"HBM bytes per launch (rocprofv3 PMC passes, profiles/{traffic_src})",
-                         "kernel_ms": round(pbs_ms, 3), "keyswitch_kernel_ms": round(ks_ms, 3)},
+                         "kernel_ms": round(pbs_ms, 3), "keyswitch_kernel_ms": round(ks_ms, 3), "counters": measured_issue_profile()},
         }
         if gathered is not None:
             line["gathered_ciphertexts"] = int(gathered[0] * gathered[1])
