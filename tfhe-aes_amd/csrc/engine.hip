@@ -65,11 +65,11 @@ struct tfa_ctx {
     bool ks_valu = false;  // TFA_KS_VALU=1: keep the keyswitch on the vector ALUs (the generic-parameter path; for comparison)
     bool trace = false;   // TFA_TRACE=1: one stderr line per submitted stage
     bool lat_asm = true;  // TFA_LAT_ASM=0: the one-bootstrap-per-workgroup mapping runs the compiler-scheduled kernel
-    bool pbs_asm = true;  // TFA_PBS_ASM=0: the 8-wave mapping runs the compiler-scheduled kernel instead of the hand-scheduled loop
+    bool pbs_asm = true;  // TFA_PBS_ASM=0: the one-bootstrap-per-wave mappings run the compiler-scheduled kernels instead of the hand-scheduled loop
     // time of one round of workgroups over all CUs per mapping, microseconds: [0] 8 bootstraps per workgroup, [1] 4 per
     // workgroup, [2] one bootstrap per workgroup and one workgroup per CU, [3] the same with two workgroups per CU.
     // Measured on this device after the key upload (calibrate_rounds); the defaults are an MI355X at 2.4 GHz.
-    double round_us[4] = {10000, 7600, 3000, 5100};
+    double round_us[4] = {9800, 6600, 2400, 4100};
     int force_waves = 0;  // 0 = choose per launch; 1 / 2 (latency kernel, workgroups per CU), 4 or 8 pins the kernel variant (TFA_PBS_WAVES, for experiments)
     std::vector<EventPair> pending;
     // per-stage validation marks, sized with the pool: slot_mark[s] = stamp of the stage that last wrote s,
