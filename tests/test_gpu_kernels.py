@@ -37,8 +37,8 @@ def test_keyswitch_bit_exact(gpu_ctx, oracle, okeys):
 
 
 def test_keyswitch_tile_sizes_bit_exact(gpu_ctx, oracle, okeys):
-    """Every tile width of the keyswitch kernel, with and without the split over input coefficients
-    that narrow batches use (partial sums combined with integer atomics)."""
+    """Batch sizes from one gate to many gate tiles: the matrix-core keyswitch with every split of the input
+    coefficients that the engine picks (24-fold for one tile down to unsplit; partial sums combined with integer atomics)."""
     rng = np.random.default_rng(2)
     for count in (1, 37, 300, 1100, 2500, 8200):
         big = rng.integers(0, 2**32, (count, gpu_ctx.big + 1), dtype=np.uint64).astype(np.uint32)
@@ -52,8 +52,8 @@ def test_keyswitch_tile_sizes_bit_exact(gpu_ctx, oracle, okeys):
 
 
 def test_keyswitch_vector_path_bit_exact(oracle, okeys):
-    """The vector-ALU keyswitch kernels (generic parameters; narrow stages in production) at the batch sizes
-    where production would pick the matrix-core kernel: pinned with TFA_KS_VALU=1."""
+    """The vector-ALU keyswitch kernels (other parameter sets in production; the default set always takes the
+    matrix-core kernel), every tile width with and without the split over input coefficients: pinned with TFA_KS_VALU=1."""
     import os
     os.environ["TFA_KS_VALU"] = "1"
     try:
@@ -63,7 +63,7 @@ def test_keyswitch_vector_path_bit_exact(oracle, okeys):
     try:
         ctx.keys_upload(okeys[2], okeys[3])
         rng = np.random.default_rng(3)
-        for count in (300, 2500, 8200):
+        for count in (1, 37, 300, 2500, 8200):
             big = rng.integers(0, 2**32, (count, ctx.big + 1), dtype=np.uint64).astype(np.uint32)
             got = ctx.keyswitch_batch(big)
             for i in (0, count // 3, count - 1):

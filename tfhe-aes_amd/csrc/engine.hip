@@ -64,6 +64,8 @@ struct tfa_ctx {
     uint32_t n_cus = 256;
     bool ks_valu = false;  // TFA_KS_VALU=1: keep the keyswitch on the vector ALUs (the generic-parameter path; for comparison)
     bool trace = false;   // TFA_TRACE=1: one stderr line per submitted stage
+    uint32_t ks_mfma_min = 1;    // fewest gates of a stage that go to the matrix-core keyswitch (TFA_KS_MFMA_MIN, experiments)
+    int ks_split = 0;     // TFA_KS_SPLIT=n (1..24): pins the matrix-core keyswitch's split of the input coefficients (tests)
     bool lat_asm = true;  // TFA_LAT_ASM=0: the one-bootstrap-per-workgroup mapping runs the compiler-scheduled kernel
     bool pbs_asm = true;  // TFA_PBS_ASM=0: the one-bootstrap-per-wave mappings run the compiler-scheduled kernels instead of the hand-scheduled loop
     // time of one round of workgroups over all CUs per mapping, microseconds: [0] 8 bootstraps per workgroup, [1] 4 per
@@ -214,6 +216,8 @@ extern "C" int tfa_ctx_create(const tfa_params *p, int hip_device, tfa_ctx **out
     if (const char *t = getenv("TFA_KS_VALU")) ctx->ks_valu = atoi(t) != 0;
     if (const char *t = getenv("TFA_PBS_ASM")) ctx->pbs_asm = atoi(t) != 0;
     if (const char *t = getenv("TFA_LAT_ASM")) ctx->lat_asm = atoi(t) != 0;
+    if (const char *t = getenv("TFA_KS_MFMA_MIN")) ctx->ks_mfma_min = (uint32_t)atoi(t);
+    if (const char *t = getenv("TFA_KS_SPLIT")) ctx->ks_split = atoi(t) < 1 ? 0 : (atoi(t) > 24 ? 24 : atoi(t));
     if (const char *w = getenv("TFA_PBS_WAVES")) ctx->force_waves = (atoi(w) == 8 || atoi(w) == 4 || atoi(w) == 2 || atoi(w) == 1) ? atoi(w) : 0;
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     // per-lane twiddles e^{i pi t (1 + 4 r)/512}, [r][t]
@@ -591,10 +595,25 @@ static int launch_ks(tfa_ctx *ctx, const KsJob *d_jobs, uint32_t n_jobs, uint32_
         HIPCHK(ctx, hipEventRecord(ep.a, ctx->stream));
     }
     const uint32_t big_dim = p.glwe_dimension * p.polynomial_size;
-    // From one workgroup tile of gates per CU upwards the int8 matrix cores win (3.7 ms against 29 ms for 65536 gates);
-    // narrower stages are latency-bound and stay on the vector kernels, which split the key stream over all CUs.
-    if (ctx->d_ksk8 && !ctx->ks_valu && n_jobs >= 256) {
-        hipLaunchKernelGGL(keyswitch_mfma_kernel<5>, dim3((n_jobs + kKsmGates - 1) / kKsmGates, (p.lwe_dimension + 1 + kKsmCols - 1) / kKsmCols), dim3(256), 0,
+    // With the default parameter set every stage goes to the int8 matrix cores (65 536 gates: 3.7 ms against 29 ms for the
+    // vector kernel; 128 gates: 37 us against 111 us; 16 gates: 22 us against 39 us); the vector kernels serve other
+    // parameter sets and TFA_KS_VALU=1.
+    if (ctx->d_ksk8 && !ctx->ks_valu && n_jobs >= ctx->ks_mfma_min) {
+        // A workgroup walks its blocks of 64 input coefficients one after the other, about 9 us each: alone on its CU it is
+        // latency-bound.  While the gate tiles are fewer than about 1.5 workgroups per CU the blocks are split over several
+        // workgroups that add their partial sums with integer atomics (measured best: 128 gates 24-fold, 37 us against 223 us
+        // unsplit and 111 us for the vector kernel; 512 gates 8-fold, 59 us; 2 048 gates 2-fold, 147 us; from 3 840 gates unsplit).
+        const uint32_t tiles = (n_jobs + kKsmGates - 1) / kKsmGates, col_tiles = (p.lwe_dimension + 1 + kKsmCols - 1) / kKsmCols;
+        const uint32_t n_kb = big_dim / kKsmCoefs;
+        uint32_t split = (3 * ctx->n_cus / 2 + tiles * col_tiles - 1) / (tiles * col_tiles);
+        if (split > n_kb) split = n_kb;
+        if (ctx->ks_split >= 1) split = (uint32_t)ctx->ks_split;
+        if (split > 1) {
+            hipLaunchKernelGGL(keyswitch_init_kernel, dim3(n_jobs), dim3(256), 0, ctx->stream, big_base, ctx->big_stride, d_jobs, n_jobs,
+                               p.lwe_dimension, big_dim, out_base, out_stride);
+            HIPCHK(ctx, hipGetLastError());
+        }
+        hipLaunchKernelGGL(keyswitch_mfma_kernel<5>, dim3(tiles, col_tiles, split), dim3(256), 0,
                            ctx->stream, big_base, ctx->big_stride, d_jobs, n_jobs, ctx->d_ksk8, p.lwe_dimension, big_dim, p.ks_base_log, out_base,
                            out_stride);
         HIPCHK(ctx, hipGetLastError());

@@ -174,7 +174,11 @@ __global__ void __launch_bounds__(256, 2)
             task_b[r] = jobs[gi].b;
         }
     }
-    for (uint32_t kb = 0; kb < n_kb; kb++) {
+    // gridDim.z > 1: the input coefficients are split over that many workgroups, which add their partial sums into rows
+    // initialised by keyswitch_init_kernel (integer atomics: the order does not matter, the result is exact)
+    const bool split = gridDim.z > 1;
+    const uint32_t kb_begin = (uint32_t)((uint64_t)n_kb * blockIdx.z / gridDim.z), kb_end = (uint32_t)((uint64_t)n_kb * (blockIdx.z + 1) / gridDim.z);
+    for (uint32_t kb = kb_begin; kb < kb_end; kb++) {
         __syncthreads();  // the previous block's digit reads are done
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -238,6 +242,10 @@ __global__ void __launch_bounds__(256, 2)
             if (gi >= n_jobs) continue;
             const KsJob jb = jobs[gi];
             uint32_t v = 0u - ((uint32_t)acc[m][0][r] + ((uint32_t)acc[m][1][r] << 8) + ((uint32_t)acc[m][2][r] << 16) + ((uint32_t)acc[m][3][r] << 24));
+            if (split) {
+                atomicAdd(out_base + (size_t)jb.out * out_stride + col, v);
+                continue;
+            }
             if (col == n) {
                 v += big[(size_t)jb.a * big_stride + big_dim] + jb.cst;
                 if (jb.b != kNoSlot) v += big[(size_t)jb.b * big_stride + big_dim];
