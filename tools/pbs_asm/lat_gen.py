@@ -14,14 +14,15 @@ under the other's butterfly; complex products are two multiplies and two multipl
 are read from a small LDS table when needed (registers: 128 key words + 28 twiddle words + data); the waits come
 from gen.place_waits().  tools/pbs_asm/lat_emu.py executes the emitted text on the CPU against the exact oracle.
 
-Register map (VGPR): v1 rotation write address | v2 rotation region base | v3 L | v4-7 hand-over base address of stage
-0-3 | v8 spectrum write base | v9-11 spectrum read bases of the polynomials (w + 1, 2, 3) & 3 | v12 key offset (16 L) |
-v13 stage-twiddle table address | v14-17 the four addresses above with the step parity added | v18 next rotation
-amount | v19-29 scratch | v30-31 1.5 * 2^52 | v32-39 accumulator | v40-55 twist | v56-67 stage-0 twiddles |
-v68-83 / v84-99 data of level 1 / 2 as (re, im) quads; the spectra read from the other waves | v100-115 output sums |
-v116-127 (+ whatever of v68-115 is free in a phase) temporaries | v128-255 key words [level][k][q], k = polynomial
-(w + k) & 3.   SGPR: s10 steps left | s11 address of a_tilde[i + 1] | s12 rotation amount | s13 parity offset |
-s14-15 scratch | s20-35 key pointers per (level, k) | s40+ constants.
+Register map (VGPR): v2 rotation buffer of this wave | v3 L | v4-6 / v7, v28, v29 the lane's first element in hand-over
+e's layout at stage e / e + 1 | v8 spectrum write base | v9-11 spectrum read bases of the polynomials (w + 1, 2, 3) & 3 |
+v12 key offset (16 L) | v13 stage-twiddle table address | v14-17 the four spectrum addresses with the step parity added |
+v18 next rotation amount | v19-27 scratch | v30-31 1.5 * 2^52 | v32-39 accumulator (negated) | v40-55 twist | v56-67
+stage-0 twiddles | v68-83 / v84-99 data of level 1 / 2 as (re, im) quads; the spectra read from the other waves |
+v100-115 output sums | v116-127 (+ whatever of v68-115 is free in a phase) temporaries | v128-255 key words
+[level][k][q], k = polynomial (w + k) & 3.   SGPR: s10 steps left | s11 address of a_tilde[i + 1] | s12 rotation amount |
+s13 parity offset | s14-15 scratch | s16, s17 the constants 2^11 and 511 | s20-35 key pointers per (level, k) | s36-37
+twiddle table in global memory (preamble).  M0 = this wave's rotation buffer (ds_write_addtid_b32).
 """
 import math
 import os
@@ -392,7 +393,8 @@ def place_waits_lat(lines):
 
 def experiment_filter(lines, flags):
     """timing experiments (results become garbage): nokey drops the key loads of the loop, nobar the barrier, nowait the
-    LDS waits, noho the hand-overs between stages, nospec the reads of the other waves' spectra"""
+    LDS waits, noho the hand-overs between stages, nospec the reads of the other waves' spectra; duptw keeps the results and
+    issues every twiddle read twice"""
     out, in_loop = [], False
     for ln in lines:
         op = ln.split()[0]
@@ -409,6 +411,9 @@ def experiment_filter(lines, flags):
         if "nospec" in flags and op == "ds_read_b128" and any(", v%d " % r in ln + " " for r in V_SPECRD_CUR):
             continue
         out.append(ln)
+        # duptw (results stay exact): every stage-twiddle read issued twice, to price one more LDS instruction
+        if in_loop and "duptw" in flags and op == "ds_read_b128" and ", v%d " % V_TWADDR in ln + " ":
+            out.append(ln)
     return out
 
 
