@@ -3,13 +3,13 @@
 
 Emits tfhe-aes_amd/csrc/pbs_asm_loop.inc: one inline-asm body holding the whole step loop of the 8-wave bootstrap kernel
 (rotation, signed decomposition, two forward negacyclic transforms, multiply-accumulate with the key ring, inverse
-transform, rounding), with every register chosen here and every LDS wait placed by hand.  The arithmetic is that of
-csrc/pbs_kernel.h (same lane mapping, LDS layout, key layout and twiddle table), with the constant twiddle scalings
-folded into fused multiply-adds.  tools/pbs_asm/emu.py executes the emitted text on the CPU against the exact oracle.
+transform, rounding), with every register chosen here and every LDS wait derived by place_waits().  The arithmetic is that of
+csrc/pbs_kernel.h (same lane mapping, key layout and twiddle table; its own LDS layout: K_* below), with the constant twiddle
+scalings folded into fused multiply-adds, the accumulator kept negated and the rotation buffer interleaved by polynomial.  tools/pbs_asm/emu.py executes the emitted text on the CPU against the exact oracle.
 
-Register map (VGPR):  v1 rotation write address | v2 rotation region base | v3 t | v4-7 exchange store addresses |
+Register map (VGPR):  v2 rotation buffer of this wave + 4 g | v3 t | v4-7 exchange store addresses |
 v8-11 exchange row-read addresses | v16 twiddle row address | v17 lane*16 | v18 key read address | v19-31 scratch |
-v32-63 accumulator | v64-127 array A (level-1 data, then the output spectrum) | v128-191 array B (level-2 data; the
+v32-63 accumulator (negated) | v64-127 array A (level-1 data, then the output spectrum) | v128-191 array B (level-2 data; the
 inverse transform's twiddles) | v192-223 key words / twiddles / rotated coefficients | v224-255 temporaries.
 v0 and s0-s7 are left to the compiler.  Arrays keep "home slots": element k of array X has its real part in
 X + 2 k and its imaginary part in X + 32 + 2 k; butterflies read their inputs from home slots and write their outputs
