@@ -1,5 +1,6 @@
 """Soak run: ROUNDS x 65536 random two-input gates, each round feeding on the outputs of the two rounds before it;
-counts results that decrypt wrongly (expected 0).  usage: python3 tools/soak.py [ROUNDS=256]"""
+counts results that decrypt wrongly (expected 0).  usage: python3 tools/soak.py [ROUNDS=256] [GATES_PER_ROUND=65536]
+(narrow rounds exercise the one-bootstrap-per-workgroup and four-wave kernels)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tfhe-aes_amd", "py"))
@@ -7,7 +8,7 @@ import numpy as np
 from tfhe_aes_amd import engine as E
 
 ROUNDS = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-G = 65536
+G = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 p = E.default_params()
 lwe_sk, _, bsk, ksk = E.client_keygen(p, 77)
 ctx = E.Context(p, 0); ctx.keys_upload(bsk, ksk); ctx.pool_reserve(3 * G)
