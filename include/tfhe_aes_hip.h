@@ -88,10 +88,13 @@ int tfa_pool_device_ptr(tfa_ctx *ctx, void **dptr, uint32_t *stride_words, uint3
 int tfa_stage_submit(tfa_ctx *ctx, const tfa_gate *gates, uint32_t count);
 int tfa_sync(tfa_ctx *ctx);
 
-/* tfa_stage_submit for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
- * forbid hipMalloc).  No counterpart in the reference.  Same gates, same results, same ordering on the context's stream,
+/* tfa_stage_submit for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc once set-up is
+ * over).  No counterpart in the reference.  Same gates, same results, same ordering on the context's stream,
  * but the stage's job lists and big-LWE intermediates live in a static device array of fixed size instead of the
- * context's grow-only buffers, and the call performs no hipMalloc / hipFree / hipHostMalloc.  Limits: at most
+ * context's grow-only buffers, and the call performs no hipMalloc / hipFree / hipHostMalloc.  It is not a graph-capture
+ * entry point: it copies the translated job lists from a pinned host buffer on the context's own stream and records an
+ * event there.  There is one such host buffer, so a call first waits until the previous call's copy has executed (host and
+ * device run at most one call apart; tfa_stage_submit has a ring of four).  Limits: at most
  * TFA_NOALLOC_MAX_GATES gates and TFA_NOALLOC_MAX_PBS bootstraps (a MUX counts two) per call; larger stages return
  * TFA_EINVAL.  Each GPU holds one copy of the array (TFA_NOALLOC_SCRATCH_BYTES) until the process ends; all contexts
  * on a GPU share it and it keeps the previous call's contents, so calls that overlap on one GPU (two contexts, two
@@ -111,6 +114,17 @@ int tfa_keyswitch_batch(tfa_ctx *ctx, const uint32_t *big_in /*[count][kN+1]*/, 
 int tfa_set_profiling(tfa_ctx *ctx, int on); /* HIP events around each kernel on the context stream */
 int tfa_get_stats(tfa_ctx *ctx, tfa_stats *out);
 int tfa_reset_stats(tfa_ctx *ctx);
+/* The timed launches behind tfa_stats, one record each, in submission order since the last tfa_reset_stats (only while
+ * profiling is on): what the reference prints with Instant::now() around a mode call
+ * (/root/reference/tfhe-aes/src/main.rs:154-163), resolved per stage.  kind 0 = the bootstraps of a stage (units =
+ * bootstraps; mapping = bootstraps per workgroup of the kernel that ran them: 8 or 4 = one wave each, 1 or 2 = one
+ * bootstrap per workgroup with that many workgroups per CU, 8 | tail << 8 = whole rounds of the 8-per-workgroup kernel
+ * plus a tail), kind 1 = its keyswitches.  Synchronises the stream; writes min(capacity, *count) records, *count = all. */
+typedef struct tfa_launch_record {
+    uint32_t units, kind, mapping;
+    float ms;
+} tfa_launch_record;
+int tfa_profile_launches(tfa_ctx *ctx, tfa_launch_record *out, uint32_t capacity, uint32_t *count);
 const char *tfa_last_error(tfa_ctx *ctx);
 
 /* Client side (ClientKey::{encrypt,decrypt} and the key-material half of gen_keys();

@@ -43,6 +43,16 @@ pub struct tfa_stats {
     pub ks_launches: u64,
 }
 
+/// One timed launch (profiling on): kind 0 = the bootstraps of a stage, 1 = its keyswitches.
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct tfa_launch_record {
+    pub units: u32,
+    pub kind: u32,
+    pub mapping: u32,
+    pub ms: f32,
+}
+
 #[repr(C)]
 pub struct tfa_ctx {
     _private: [u8; 0],
@@ -91,6 +101,7 @@ extern "C" {
     pub fn tfa_set_profiling(ctx: *mut tfa_ctx, on: c_int) -> c_int;
     pub fn tfa_get_stats(ctx: *mut tfa_ctx, out: *mut tfa_stats) -> c_int;
     pub fn tfa_reset_stats(ctx: *mut tfa_ctx) -> c_int;
+    pub fn tfa_profile_launches(ctx: *mut tfa_ctx, out: *mut tfa_launch_record, capacity: u32, count: *mut u32) -> c_int;
     pub fn tfa_client_keygen(p: *const tfa_params, seed: u64, lwe_sk: *mut u32, glwe_sk: *mut u32, bsk: *mut u32, ksk: *mut u32) -> c_int;
     pub fn tfa_client_encrypt(p: *const tfa_params, lwe_sk: *const u32, seed: u64, bits: *const u8, count: u32, lwe_out: *mut u32) -> c_int;
     pub fn tfa_client_decrypt(p: *const tfa_params, lwe_sk: *const u32, lwe: *const u32, count: u32, bits_out: *mut u8) -> c_int;

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/tfhe_aes_hip.h"
@@ -22,11 +23,13 @@ using namespace tfa;
 namespace {
 constexpr size_t kAsmKeySlackBytes = 131072;  // one blind-rotation step of Fourier key
 constexpr uint32_t kPoolStridePad = 4;   // pool rows padded to a multiple of 4 words (16 B)
+constexpr size_t kMaxLaunchRecords = 1u << 20;  // tfa_profile_launches keeps at most this many records between resets
 constexpr int kStagingRing = 4;
 
 struct EventPair {
     hipEvent_t a, b;
     int kind;  // 0 = pbs, 1 = ks
+    uint32_t units = 0, mapping = 0;  // bootstraps / keyswitches of the launch; bootstrap mapping (tfa_launch_record)
 };
 }  // namespace
 
@@ -74,6 +77,7 @@ struct tfa_ctx {
     double round_us[4] = {9800, 6600, 2400, 4100};
     int force_waves = 0;  // 0 = choose per launch; 1 / 2 (latency kernel, workgroups per CU), 4 or 8 pins the kernel variant (TFA_PBS_WAVES, for experiments)
     std::vector<EventPair> pending;
+    std::vector<tfa_launch_record> launches;  // one record per timed bootstrap / keyswitch launch since the last reset (profiling only)
     // per-stage validation marks, sized with the pool: slot_mark[s] = stamp of the stage that last wrote s,
     // lin_reader[s] = (stamp << 32) | index + 1 of the NOT/COPY gate reading s (all ones: several)
     std::vector<uint32_t> slot_mark;
@@ -163,6 +167,7 @@ static int drain_events(tfa_ctx *ctx) {
             ctx->stats.ks_kernel_ms += ms;
             ctx->stats.ks_launches++;
         }
+        if (ctx->launches.size() < kMaxLaunchRecords) ctx->launches.push_back(tfa_launch_record{ep.units, (uint32_t)ep.kind, ep.mapping, ms});
         hipEventDestroy(ep.a);
         hipEventDestroy(ep.b);
     }
@@ -475,22 +480,38 @@ static void launch_variant(tfa_ctx *ctx, int variant, const uint32_t *in_base, u
                            ctx->d_bsk_lat, ctx->d_tw_lat, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
 }
 
-// Round times of the four mappings on this device: each mapping runs one full round of workgroups for two step counts,
-// and the line through the two timings gives the time of a complete blind rotation (slope) plus the launch's fixed part.
-// Results are kept per device for the life of the process; TFA_NO_CALIBRATE=1 keeps the built-in table.
+// Round times of the four mappings on this device: each mapping runs one full round of workgroups for two step counts
+// (a quarter and three quarters of the blind rotation's length, so both lie inside what the kernels execute), and the line
+// through the two timings gives the time of a complete blind rotation (slope) plus the launch's fixed part.  A table belongs
+// to one (device, LWE dimension, kernel selection) and is kept for the life of the process; a context with another key
+// length or with TFA_PBS_ASM=0 / TFA_LAT_ASM=0 measures its own.  The table is a scheduling heuristic: when the timings make no
+// sense (non-positive slope) or the rotation is too short to time, the built-in table stays and the key upload succeeds.
+// TFA_NO_CALIBRATE=1 keeps the built-in table.
 namespace {
 struct RoundTable {
-    bool valid = false;
+    int device;
+    uint32_t lwe_dimension;
+    bool pbs_asm, lat_asm;
     double us[4];
 };
-RoundTable g_round_table[64];
+std::vector<RoundTable> g_round_tables;
+std::mutex g_round_tables_mutex;
 }  // namespace
 
 static int calibrate_rounds(tfa_ctx *ctx) {
-    if (getenv("TFA_NO_CALIBRATE") || ctx->device >= 64) return TFA_OK;
-    RoundTable &tab = g_round_table[ctx->device];
-    if (!tab.valid) {
-        const uint32_t cus = ctx->n_cus, max_jobs = 8 * cus, n = ctx->p.lwe_dimension;
+    if (getenv("TFA_NO_CALIBRATE")) return TFA_OK;
+    const uint32_t n = ctx->p.lwe_dimension;
+    if (n < 64) {  // too few steps for a slope that stands out of the launch overhead
+        if (ctx->trace) fprintf(stderr, "tfa round times: lwe_dimension %u too short to calibrate, built-in table kept\n", n);
+        return TFA_OK;
+    }
+    std::lock_guard<std::mutex> lock(g_round_tables_mutex);
+    const RoundTable *found = nullptr;
+    for (const auto &t : g_round_tables)
+        if (t.device == ctx->device && t.lwe_dimension == n && t.pbs_asm == ctx->pbs_asm && t.lat_asm == ctx->lat_asm) found = &t;
+    if (!found) {
+        RoundTable tab{ctx->device, n, ctx->pbs_asm, ctx->lat_asm, {0, 0, 0, 0}};
+        const uint32_t cus = ctx->n_cus, max_jobs = 8 * cus;
         uint32_t *d_in = nullptr, *d_big = nullptr;
         PbsJob *d_jobs = nullptr;
         HIPCHK(ctx, hipMalloc(&d_in, 2 * (size_t)ctx->pool_stride * sizeof(uint32_t)));
@@ -505,7 +526,8 @@ static int calibrate_rounds(tfa_ctx *ctx) {
         for (auto &x : ev)
             if (e == hipSuccess) e = hipEventCreate(&x);
         const int variants[4] = {8, 4, 1, 2};
-        const uint32_t widths[4] = {8 * cus, 4 * cus, cus, 2 * cus}, s0 = 100, s1 = 300;
+        const uint32_t widths[4] = {8 * cus, 4 * cus, cus, 2 * cus}, s0 = n / 4, s1 = n - n / 4;
+        bool sane = true;
         // the shader clock takes a few milliseconds of load to come up from idle: one complete round first
         if (e == hipSuccess) launch_variant(ctx, 8, d_in, ctx->pool_stride, d_jobs, widths[0], n, d_big, nullptr, true);
         for (int v = 0; v < 4 && e == hipSuccess; v++) {
@@ -522,7 +544,7 @@ static int calibrate_rounds(tfa_ctx *ctx) {
             if (e == hipSuccess) e = hipEventElapsedTime(&ms1, ev[1], ev[2]);
             const double per_step = (ms1 - ms0) / (double)(s1 - s0), fixed = ms0 - per_step * s0;
             tab.us[v] = 1000.0 * (per_step * n + (fixed > 0 ? fixed : 0));
-            if (!(per_step > 0)) e = hipErrorUnknown;
+            if (!(per_step > 0)) sane = false;
         }
         for (auto &x : ev)
             if (x) hipEventDestroy(x);
@@ -530,10 +552,16 @@ static int calibrate_rounds(tfa_ctx *ctx) {
         hipFree(d_big);
         hipFree(d_jobs);
         if (e != hipSuccess) return fail(ctx, TFA_EHIP, std::string("round-time calibration: ") + hipGetErrorString(e));
-        tab.valid = true;
+        if (!sane) {  // a timing anomaly must not fail the key upload: keep the defaults for this context, measure again next time
+            if (ctx->trace) fprintf(stderr, "tfa round times: calibration gave a non-positive slope, built-in table kept\n");
+            return TFA_OK;
+        }
+        g_round_tables.push_back(tab);
+        found = &g_round_tables.back();
     }
-    for (int v = 0; v < 4; v++) ctx->round_us[v] = tab.us[v];
-    if (ctx->trace) fprintf(stderr, "tfa round times (us): 8/wg %.0f, 4/wg %.0f, 1 wg/CU %.0f, 2 wg/CU %.0f\n", tab.us[0], tab.us[1], tab.us[2], tab.us[3]);
+    for (int v = 0; v < 4; v++) ctx->round_us[v] = found->us[v];
+    if (ctx->trace)
+        fprintf(stderr, "tfa round times (us): 8/wg %.0f, 4/wg %.0f, 1 wg/CU %.0f, 2 wg/CU %.0f\n", found->us[0], found->us[1], found->us[2], found->us[3]);
     return TFA_OK;
 }
 
@@ -565,13 +593,17 @@ static int launch_pbs(tfa_ctx *ctx, const uint32_t *in_base, uint32_t in_stride,
     int variant = 0, tail_variant = 0;
     const double t_single = best_single(n_jobs, variant);
     const uint32_t full = (uint32_t)((n_jobs / (8 * cus)) * (8 * cus));
+    ep.units = n_jobs;
     if (ctx->force_waves) {
+        ep.mapping = (uint32_t)ctx->force_waves;
         launch(ctx->force_waves, 0, n_jobs);
     } else if (full > 0 && full < n_jobs && (double)(full / (8 * cus)) * r8 + best_single(n_jobs - full, tail_variant) < t_single) {
+        ep.mapping = 8u | ((uint32_t)tail_variant << 8);
         launch(8, 0, full);
         HIPCHK(ctx, hipGetLastError());
         launch(tail_variant, full, n_jobs - full);
     } else {
+        ep.mapping = (uint32_t)variant;
         launch(variant, 0, n_jobs);
     }
     HIPCHK(ctx, hipGetLastError());
@@ -587,7 +619,7 @@ static int launch_ks(tfa_ctx *ctx, const KsJob *d_jobs, uint32_t n_jobs, uint32_
                      bool timed = true) {
     if (n_jobs == 0) return TFA_OK;
     const tfa_params &p = ctx->p;
-    EventPair ep{nullptr, nullptr, 1};
+    EventPair ep{nullptr, nullptr, 1, n_jobs, 0};
     const bool profiling = ctx->profiling && timed;
     if (profiling) {
         HIPCHK(ctx, hipEventCreate(&ep.a));
@@ -932,7 +964,17 @@ extern "C" int tfa_reset_stats(tfa_ctx *ctx) {
     if (!ctx) return TFA_EINVAL;
     int rc = tfa_sync(ctx);
     ctx->stats = tfa_stats{};
+    ctx->launches.clear();
     return rc;
+}
+extern "C" int tfa_profile_launches(tfa_ctx *ctx, tfa_launch_record *out, uint32_t capacity, uint32_t *count) {
+    if (!ctx || !count || (capacity && !out)) return TFA_EINVAL;
+    int rc = tfa_sync(ctx);  // drains the pending events into the records
+    if (rc) return rc;
+    const uint32_t have = (uint32_t)ctx->launches.size(), n = have < capacity ? have : capacity;
+    for (uint32_t i = 0; i < n; i++) out[i] = ctx->launches[i];
+    *count = have;
+    return TFA_OK;
 }
 
 #ifdef TFA_STAMPS

@@ -218,6 +218,26 @@ class Context:
     def reset_stats(self):
         self._chk(self.lib.tfa_reset_stats(self._ctx), "tfa_reset_stats")
 
+    def profile_launches(self):
+        return profile_launches(self.lib, self._ctx)
+
+
+LAUNCH_DTYPE = np.dtype([("units", np.uint32), ("kind", np.uint32), ("mapping", np.uint32), ("ms", np.float32)])
+
+
+def profile_launches(lib, ctx):
+    """tfa_profile_launches: every timed launch since the last reset as a structured array (units, kind, mapping, ms)"""
+    n = C.c_uint32(0)
+    rc = lib.tfa_profile_launches(ctx, None, C.c_uint32(0), C.byref(n))
+    if rc != 0:
+        raise RuntimeError("tfa_profile_launches failed (%d)" % rc)
+    out = np.zeros(n.value, LAUNCH_DTYPE)
+    if n.value:
+        rc = lib.tfa_profile_launches(ctx, out.ctypes.data_as(C.c_void_p), C.c_uint32(n.value), C.byref(n))
+        if rc != 0:
+            raise RuntimeError("tfa_profile_launches failed (%d)" % rc)
+    return out
+
 
 def make_gates(ops, in0, in1, in2, out, neg=None):
     ops = np.asarray(ops)

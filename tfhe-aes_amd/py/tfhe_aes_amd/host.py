@@ -72,6 +72,9 @@ class Keys:
     def reset_engine_stats(self):
         E.load_library().tfa_reset_stats(C.c_void_p(_lib().tfh_context(self.h)))
 
+    def profile_launches(self):
+        return E.profile_launches(E.load_library(), C.c_void_p(_lib().tfh_context(self.h)))
+
     # ciphertext-level API (ClientKey / ServerKey)
     def encrypt(self, message):
         h = C.c_void_p()

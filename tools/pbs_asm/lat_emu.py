@@ -146,8 +146,8 @@ def main():
             for k in range(4):
                 p = (w + k) & 3
                 off = ((lv * 4 + p) * 4 + w) * 4 * 64 * 16
-                M.s[LG.S_KEY + 2 * (lv * 4 + k)][w] = off
-                M.s[LG.S_KEY + 2 * (lv * 4 + k) + 1][w] = 0
+                M.s[LG.key_sreg(lv * 4 + k)][w] = off
+                M.s[LG.key_sreg(lv * 4 + k) + 1][w] = 0
     lines = [ln.replace("%=", "") for ln in LG.Lat().build()]
     M.run(lines)
     ref = o.blind_rotate(bsk, None, ct, steps)       # [4][512]

@@ -21,8 +21,8 @@ v18 next rotation amount | v19-27 scratch | v30-31 1.5 * 2^52 | v32-39 accumulat
 stage-0 twiddles | v68-83 / v84-99 data of level 1 / 2 as (re, im) quads; the spectra read from the other waves |
 v100-115 output sums | v116-127 (+ whatever of v68-115 is free in a phase) temporaries | v128-255 key words
 [level][k][q], k = polynomial (w + k) & 3.   SGPR: s10 steps left | s11 address of a_tilde[i + 1] | s12 rotation amount |
-s13 parity offset | s14-15 scratch | s16, s17 the constants 2^11 and 511 | s20-35 key pointers per (level, k) | s36-37
-twiddle table in global memory (preamble).  M0 = this wave's rotation buffer (ds_write_addtid_b32).
+s13 parity offset | s14-15 scratch | s16, s17 the constants 2^11 and 511 | s20-31, s34-37 key pointers per (level, k) |
+s38-39 twiddle table in global memory (preamble).  M0 = this wave's rotation buffer (ds_write_addtid_b32).
 """
 import math
 import os
@@ -54,8 +54,13 @@ MAGIC = 6755399441055744.0
 S_STEPS, S_ACUR, S_A, S_PAR, S_TMP = 10, 11, 12, 13, 14
 S_C2048 = 16
 S_C511 = 17
-S_TW = 36                                 # s[36:37] twiddle table in global memory (prologue only)
-S_KEY = 20                                # s[20 + 2 j : 21 + 2 j], j = lv * 4 + k
+S_TW = 38                                 # s[38:39] twiddle table in global memory (prologue only)
+
+
+def key_sreg(j):
+    """first scalar register of key pointer j = lv * 4 + k: s[20:31] and s[34:37]; s[32:33] are left alone (the compiler
+    reserves s32 as stack pointer, and an asm statement that changes it would break any call the kernel ever makes)"""
+    return 20 + 2 * j if j < 6 else 22 + 2 * j
 
 V_ROTBASE, V_L = 2, 3
 V_PA = [4, 5, 6]                          # lane's position in hand-over e's layout at stage e
@@ -271,7 +276,7 @@ class Lat:
         for lv in (0, 1):
             j = lv * 4 + k
             for q in range(4):
-                e("global_load_dwordx4 %s, v%d, s[%d:%d] offset:%d" % (qreg(R_KEY + (j * 4 + q) * 4), V_KOFF, S_KEY + 2 * j, S_KEY + 2 * j + 1, q * 1024))
+                e("global_load_dwordx4 %s, v%d, s[%d:%d] offset:%d" % (qreg(R_KEY + (j * 4 + q) * 4), V_KOFF, key_sreg(j), key_sreg(j) + 1, q * 1024))
 
     def inverse(self):
         e = self.e
@@ -329,8 +334,8 @@ class Lat:
 
     def advance_key_pointers(self):
         for j in range(8):
-            self.e("s_add_u32 s%d, s%d, 0x%x" % (S_KEY + 2 * j, S_KEY + 2 * j, STEP_KEY_BYTES))
-            self.e("s_addc_u32 s%d, s%d, 0" % (S_KEY + 2 * j + 1, S_KEY + 2 * j + 1))
+            self.e("s_add_u32 s%d, s%d, 0x%x" % (key_sreg(j), key_sreg(j), STEP_KEY_BYTES))
+            self.e("s_addc_u32 s%d, s%d, 0" % (key_sreg(j) + 1, key_sreg(j) + 1))
 
     def build(self):
         e = self.e
@@ -425,7 +430,7 @@ def main():
         lines = experiment_filter(lines, flags)
     v, s = G.clobbers(lines)
     inputs_v = set([V_ROTBASE, V_L] + V_PA + V_PB + [V_SPECWR] + V_SPECRD + [V_KOFF, V_TWADDR]) | set(range(V_ACC, V_ACC + 8))
-    inputs_s = set([S_STEPS, S_ACUR, S_A, S_PAR, S_TW, S_TW + 1]) | set(range(S_KEY, S_KEY + 16))
+    inputs_s = set([S_STEPS, S_ACUR, S_A, S_PAR, S_TW, S_TW + 1]) | set(key_sreg(j) + h for j in range(8) for h in (0, 1))
     assert 0 not in v and not (set(range(0, 8)) & set(s)), "v0 / s0-s7 belong to the compiler"
     cl = ['"v%d"' % r for r in v if r not in inputs_v] + ['"s%d"' % r for r in s if r not in inputs_s]
     out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "..", "..", "tfhe-aes_amd", "csrc", "pbs_lat_asm_loop.inc")
