@@ -41,7 +41,8 @@ GATES_PER_STEP = 65536
 FLOP_PER_PBS = 805 * 206848          # 12 FFT-256 + 12 twists + 32 complex vector MACs per blind-rotation step
 FP64_PEAK_TFLOPS = 78.6              # MI355X fp64 vector = matrix peak (datasheet)
 SEED = 0x5446484541455321
-PMC_SUMMARIES = ("r2_pmc_summary.json", "r1_pmc_summary.json")   # newest first
+HBM_PEAK_GBPS = 8000.0               # MI355X HBM3E
+PMC_SUMMARIES = ("r3_pmc_summary.json", "r2_pmc_summary.json", "r1_pmc_summary.json")   # newest first
 
 
 def measured_traffic():
@@ -60,17 +61,27 @@ def measured_traffic():
 
 
 def measured_issue_profile():
-    """Ratios of the dominant kernel from the same committed PMC passes (profiles/r2_pmc_summary.json, derived by
-    tools/pmc_summary.py): share of wave cycles spent waiting on LDS instructions and issuing, instructions per wave and
-    blind-rotation step, and the FMA share of the loop's fp64 instructions.  None when the file is absent."""
-    try:
-        with open(os.path.join(ROOT, "profiles", PMC_SUMMARIES[0])) as f:
-            d = json.load(f)["derived_pbs_asm_kernel"]
-        return {"sq_wait_inst_lds_per_wave_cycle": d["SQ_WAIT_INST_LDS/SQ_WAVE_CYCLES"], "sq_active_inst_any_per_wave_cycle": d["SQ_ACTIVE_INST_ANY/SQ_WAVE_CYCLES"],
-                "valu_instructions_per_wave_step": d["valu_instructions_per_wave_step"], "lds_instructions_per_wave_step": d["lds_instructions_per_wave_step"],
-                "fp64_fma_share": d["fp64_instructions_per_wave_step"]["fma_share"], "source": "profiles/" + PMC_SUMMARIES[0]}
-    except (OSError, KeyError, ValueError):
-        return None
+    """Ratios of the dominant kernel from the newest committed PMC passes (derived by tools/pmc_summary.py): share of wave
+    cycles spent waiting on LDS instructions and issuing, instructions per wave and blind-rotation step, and the FMA share
+    of the loop's fp64 instructions; `source` names the file, the commit and the kernel the counters were collected on.
+    None when no summary is readable."""
+    for name in PMC_SUMMARIES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                full = json.load(f)
+            d = full["derived_pbs_asm_kernel"]
+            src = "profiles/" + name
+            if full.get("commit"):
+                src += " @ " + str(full["commit"])[:12]
+            if full.get("kernel"):
+                src += " (" + full["kernel"] + ")"
+            return {"sq_wait_inst_lds_per_wave_cycle": d["SQ_WAIT_INST_LDS/SQ_WAVE_CYCLES"], "sq_active_inst_any_per_wave_cycle": d["SQ_ACTIVE_INST_ANY/SQ_WAVE_CYCLES"],
+                    "valu_instructions_per_wave_step": d["valu_instructions_per_wave_step"], "lds_instructions_per_wave_step": d["lds_instructions_per_wave_step"],
+                    "fp64_instructions_per_wave_step": sum(d["fp64_instructions_per_wave_step"][k] for k in ("v_fma_f64", "v_add_f64", "v_mul_f64")),
+                    "fp64_fma_share": d["fp64_instructions_per_wave_step"]["fma_share"], "source": src}
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def cpu_baseline(p, lwe_sk, bsk, ksk, budget_s=20.0):
@@ -94,8 +105,21 @@ def cpu_baseline(p, lwe_sk, bsk, ksk, budget_s=20.0):
     rate = probe / run(probe)
     count = max(probe, int(rate * budget_s) // threads * threads)
     dt = run(count)
+    # BASELINE configs[0]: one FHEByte::sub_byte (0x01 -> 0x7c, primitive.rs:438-452) stage by stage on the same host cores,
+    # every gate of a stage in one OpenMP-parallel oracle call (the reference's rayon loop, primitive.rs:253-262)
+    from oracle import boolean_tree_oracle as B
+    from oracle.subbyte_oracle import sub_byte_on_oracle
+    x = 0x01
+    cts = o.encrypt_bits(lwe_sk, 77, 0, np.array([(x >> k) & 1 for k in range(8)], np.uint8))
+    t = time.perf_counter()
+    out, n_gates = sub_byte_on_oracle(o, (lwe_sk, None, bsk, ksk), bsk_f, cts, B.S_BOX)
+    sub_byte_s = time.perf_counter() - t
+    got = o.decrypt_bits(lwe_sk, np.stack(out))
+    assert sum(int(b) << (7 - i) for i, b in enumerate(got)) == 0x7C and n_gates == 405
     return {"value": round(count / dt, 2), "unit": "gate bootstraps/s", "cores": threads, "kind": "port",
-            "sample": f"{count} of the {GATES_PER_STEP} NAND/XOR gates, oracle fp64-FFT engine, OpenMP over gates, {dt:.1f} s"}
+            "sample": f"{count} of the {GATES_PER_STEP} NAND/XOR gates, oracle fp64-FFT engine, OpenMP over gates, {dt:.1f} s",
+            "sub_byte_s": round(sub_byte_s, 3), "sub_byte_threads": threads,
+            "sub_byte_sample": "one encrypted byte 0x01 -> 0x7c through the staged S-box (405 gates, 749 bootstraps, 7 stages; BASELINE configs[0])"}
 
 
 def golden():
@@ -129,8 +153,28 @@ class Leg:
                 f"{prefix}_mean_stage_width_pbs": round(self.pbs / max(1, self.stages), 1)}
 
 
-def aes_single_gpu(device):
-    """BASELINE configs[2] and configs[3] on one GPU, every result checked against the standards' vectors."""
+WIDTH_BINS = (128, 256, 512, 1024, 2048, 4096)
+
+
+def width_table(records):
+    """Bootstrap launches of a leg (tfa_profile_launches records, kind 0) by stage width: launches, bootstraps, device
+    milliseconds and bootstraps per second, the per-width view of where a single block's time goes."""
+    rows = []
+    pbs = records[records["kind"] == 0]
+    lo = 0
+    for hi in WIDTH_BINS + (1 << 31,):
+        sel = pbs[(pbs["units"] > lo) & (pbs["units"] <= hi)]
+        if len(sel):
+            ms = float(sel["ms"].sum())
+            rows.append({"width_le": hi if hi < (1 << 31) else None, "launches": int(len(sel)), "bootstraps": int(sel["units"].sum()),
+                         "ms": round(ms, 2), "kpbs_per_s": round(float(sel["units"].sum()) / ms, 1) if ms > 0 else None})
+        lo = hi
+    ks = records[records["kind"] == 1]
+    return {"bootstrap_launches_by_width": rows, "bootstrap_ms": round(float(pbs["ms"].sum()), 2), "keyswitch_ms": round(float(ks["ms"].sum()), 2)}
+
+
+def aes_single_gpu(device, chains=True):
+    """BASELINE configs[2] and (with `chains`) configs[3] on one GPU, every result checked against the standards' vectors."""
     from tfhe_aes_amd import host as H
     g = golden()
     fb, sp = g["fips197_b"], g["sp800_38a"]
@@ -155,6 +199,18 @@ def aes_single_gpu(device):
         ecb.decrypt(state)
     out.update(leg.fields("ecb_decrypt_block"))
     out["ecb_decrypt_correct"] = state.decrypt_to_u8().hex() == fb["plaintext"]
+    # the same encryption once more with HIP events around every launch (outside the timed leg above): where the block's time goes
+    state = H.State.from_u8_enc(bytes.fromhex(fb["plaintext"]), keys)
+    keys.flush()
+    keys.reset_engine_stats()
+    keys.set_profiling(True)
+    ecb.encrypt(state)
+    keys.flush()
+    out["ecb_encrypt_block_profile"] = width_table(keys.profile_launches())
+    keys.set_profiling(False)
+    if not chains:
+        keys.close()
+        return out
     # configs[3]: online key expansion (key_schedule.rs:162-171), then 4-block CBC and OFB chains (cbc.rs:22-31, ofb.rs:22-38)
     k0 = H.Key.from_u8_enc(bytes.fromhex(sp["key"]), keys)
     with Leg(keys) as leg:
@@ -270,9 +326,12 @@ def launch_ranks(n, argv):
     this process has touched the GPU (no torch.cuda call, no HIP call): the parent only waits."""
     port = os.environ.get("MASTER_PORT") or str(free_port())
     procs = []
+    # host threads (key generation, encryption: OpenMP) are shared out over the ranks instead of every rank taking them all
+    omp = str(host_threads_per_rank(n))
+    deadline = time.monotonic() + float(os.environ.get("BENCH_TIMEOUT_S", "1500"))
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS=omp, BENCH_OMP_CAPPED="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
     # wait for all of them; when one fails, the others (stuck in the rendezvous or a collective with a dead peer) are
@@ -281,12 +340,15 @@ def launch_ranks(n, argv):
     out0 = []
     reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
     reader.start()
-    codes = [None] * n
+    codes, timed_out = [None] * n, False
     while any(c is None for c in codes):
         for r, pr in enumerate(procs):
             if codes[r] is None:
                 codes[r] = pr.poll()
-        if any(c not in (None, 0) for c in codes):
+        timed_out = any(c is None for c in codes) and time.monotonic() > deadline
+        if any(c not in (None, 0) for c in codes) or timed_out:
+            if timed_out:
+                print("[bench] ranks still running at BENCH_TIMEOUT_S: ending them", file=sys.stderr)
             for r, pr in enumerate(procs):
                 if codes[r] is None:
                     pr.terminate()
@@ -302,9 +364,19 @@ def launch_ranks(n, argv):
     reader.join(timeout=10)
     sys.stdout.write("".join(out0))
     sys.stdout.flush()
-    if any(codes):
+    if any(codes) or timed_out:
         print(f"[bench] rank exit codes {codes}", file=sys.stderr)
         raise SystemExit(1)
+
+
+def host_threads_per_rank(n):
+    """OpenMP threads each of n ranks on this node may use: the node's share (OMP_NUM_THREADS when the environment sets it,
+    else the CPUs this process may run on) divided by the ranks, at least one."""
+    try:
+        total = int(os.environ["OMP_NUM_THREADS"])
+    except (KeyError, ValueError):
+        total = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, total // max(1, n))
 
 
 def main():
@@ -326,10 +398,20 @@ def main():
         if world != args.gpus:
             raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
 
+    import datetime
     import torch
     import torch.distributed as dist
     from tfhe_aes_amd import engine as E
 
+    if world > 1 and "BENCH_OMP_CAPPED" not in os.environ and os.environ.get("LOCAL_WORLD_SIZE"):
+        # started by an external launcher (torch.distributed.run): cap this rank's OpenMP team the way launch_ranks() does
+        try:
+            import ctypes
+            ctypes.CDLL("libgomp.so.1").omp_set_num_threads(host_threads_per_rank(int(os.environ["LOCAL_WORLD_SIZE"])))
+        except OSError:
+            pass
+    # a rank that never reaches the rendezvous, or a collective that never completes, ends the run non-zero instead of hanging
+    pg_timeout = datetime.timedelta(seconds=float(os.environ.get("BENCH_RENDEZVOUS_TIMEOUT_S", "600")))
     n_dev = torch.cuda.device_count()
     if n_dev == 0 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
@@ -348,14 +430,14 @@ def main():
         if backend == "nccl":
             # CUDA tensors travel over RCCL / xGMI; CPU tensors (barriers, scalars) over gloo.  One probe collective so a
             # broken fabric ends the run here, with a non-zero exit, and not behind a green line.
-            dist.init_process_group("cpu:gloo,cuda:nccl", rank=rank, world_size=world)
+            dist.init_process_group("cpu:gloo,cuda:nccl", rank=rank, world_size=world, timeout=pg_timeout)
             probe = torch.ones(1, device=torch.device("cuda", local_rank))
             dist.all_reduce(probe)
             torch.cuda.synchronize()
             if int(probe.item()) != world:
                 raise SystemExit(f"bench.py: RCCL probe all_reduce returned {probe.item()} on rank {rank}, expected {world}")
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=pg_timeout)
     on_device = backend in ("nccl", "none")
 
     p = E.default_params()
@@ -365,7 +447,11 @@ def main():
     G = GATES_PER_STEP
     bits = np.random.default_rng(100 + rank).integers(0, 2, 2 * G).astype(np.uint8)
     ctx.pool_reserve(3 * G)
-    ctx.pool_write(np.arange(2 * G), E.client_encrypt(p, lwe_sk, 1000 + rank, bits))   # inputs resident in HBM
+    fresh = E.client_encrypt(p, lwe_sk, 1000 + rank, bits)
+    ctx.pool_write(np.arange(16), fresh[:16])                  # first touch of the staging buffers stays out of the figure below
+    t_io = time.perf_counter()
+    ctx.pool_write(np.arange(2 * G), fresh)                    # inputs resident in HBM before the timed region
+    h2d_ms = (time.perf_counter() - t_io) * 1e3
     even = np.arange(G) % 2 == 0
     gates = E.make_gates(np.where(even, E.NAND, E.XOR), np.arange(G), np.arange(G, 2 * G), None, np.arange(2 * G, 3 * G))
 
@@ -395,7 +481,10 @@ def main():
         elapsed = float(t.item())
 
     # correctness of the timed work + the one collective of the path: gather a slice of the outputs, device to device
+    ctx.pool_read(np.arange(2 * G, 2 * G + 16))
+    t_io = time.perf_counter()
     out = ctx.pool_read(np.arange(2 * G, 3 * G))
+    d2h_ms = (time.perf_counter() - t_io) * 1e3
     got = E.client_decrypt(p, lwe_sk, out)
     wrong = int((got != np.where(even, 1 - (bits[:G] & bits[G:]), bits[:G] ^ bits[G:])).sum())
     gathered = None
@@ -429,12 +518,17 @@ def main():
             "config": {"workload": "65536 independent tfhe::boolean NAND/XOR gate bootstraps per GPU (BASELINE configs[1])",
                        "gates_per_step_per_gpu": G, "params": "n=805,k=3,N=512,pbs=2^10x2,ks=2^3x5", "parallelism": f"replicas x{world}, keys replicated"},
             "wrong_results": wrong,
+            # ciphertext transfer of one batch through the boundary's host-buffer calls, outside the timed region: 2 x 65536 input
+            # ciphertexts up (tfa_pool_write, 3224 B each), 65536 results down (tfa_pool_read); pageable host memory, staged copies
+            "h2d_ms": round(h2d_ms, 2), "d2h_ms": round(d2h_ms, 2),
             # the contract's two bounds are hbm and mfma; this kernel is bound by the fp64 arithmetic peak, which on
             # MI355X is the same number for the vector units it runs on and for the matrix cores ("bound_detail")
             "roofline": {"bound": "mfma", "bound_detail": "fp64 vector FMA units (peak equal to the fp64 matrix peak)", "kernel": "pbs_asm_kernel",
                          "achieved": round(achieved, 3), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP64_PEAK_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": f"HBM bytes per launch (rocprofv3 PMC passes, profiles/{traffic_src})",
+                         "hbm_gbps": round(traffic / (pbs_ms * 1e-3) / 1e9, 1) if traffic and pbs_ms > 0 else None,
+                         "hbm_frac": round(traffic / (pbs_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if traffic and pbs_ms > 0 else None,
                          "kernel_ms": round(pbs_ms, 3), "keyswitch_kernel_ms": round(ks_ms, 3), "counters": measured_issue_profile()},
         }
         if gathered is not None:
@@ -453,8 +547,10 @@ def main():
             line["aes"] = {"ctr_blocks": n_blocks, "ctr_seconds": round(dt, 3), "ctr_s_per_block": round(dt / n_blocks, 4),
                            "ctr_all_blocks_correct": ok, "sharding": f"block b on GPU b mod {world}, keys replicated, outputs gathered"}
     if rank == 0:
-        if world == 1 and not args.no_aes:
-            line["aes"].update(aes_single_gpu(local_rank))
+        if not args.no_aes:
+            # one ECB block (configs[2]) on rank 0 at every N: the "seconds per ECB block" half of the metric; the sequential
+            # chains of configs[3] do not shard and run at N = 1 only
+            line["aes"].update(aes_single_gpu(local_rank, chains=(world == 1)))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(p, lwe_sk, bsk, ksk)
         print(json.dumps(line), flush=True)

@@ -1,18 +1,61 @@
 //! The seam: `tfhe::boolean::{gen_keys, ClientKey, ServerKey, Ciphertext}` as used by `base`
 //! (base/src/primitive.rs:5-6, boolean_tree.rs:647-651), implemented on `tfhe-aes-hip-sys`.
 //!
-//! Ciphertexts live in the engine's device pool; the host holds slot handles.  `ServerKey::not` only flips a flag
-//! on the handle: the engine folds the negation into the consumer's linear combination (`tfa_gate.neg`).
-//! Trivial ciphertexts never reach the engine: every gate resolves them here with tfhe-rs' rules.
-//! Errors from the engine panic, as every failure in the reference does (`unwrap`/`expect`).
+//! Ciphertexts live in the engine's device pool; the host holds reference-counted slot handles, and a slot goes back
+//! to the pool's free list when its last handle is dropped.  `ServerKey::not` only flips a flag on the handle: the
+//! engine folds the negation into the consumer's linear combination (`tfa_gate.neg`).  Trivial ciphertexts never
+//! reach the engine: every gate resolves them here with tfhe-rs' rules.  Errors from the engine panic, as every
+//! failure in the reference does (`unwrap`/`expect`).
+//!
+//! Two ways of running gates, chosen per `ServerKey` (`set_recording`):
+//! * recording (the default): a gate call only records the gate at its dependency level, 1 + the deepest level of
+//!   its encrypted operands; `flush` (implied by every decrypt) submits level by level, one `tfa_stage_submit`
+//!   each.  Every gate that is independent at a tree height, across the 16 bytes of a state AND across all blocks
+//!   recorded since the last flush, lands in the same stage, whichever thread recorded it: the rayon loop over
+//!   blocks of modes/src/ctr.rs:26-35 and the serial loop of tfhe-aes/src/main.rs:155-157 both end up sharing
+//!   stages between blocks.
+//! * eager: `StageBatch::run` submits its gates at once as one stage (what a caller that interleaves decryptions
+//!   with gates, or wants one stage per call, asks for).
 use std::ffi::CStr;
+use std::sync::atomic::{AtomicU64, Ordering};
 use std::sync::{Arc, Mutex};
 use tfhe_aes_hip_sys as sys;
 
-#[derive(Clone, Copy, Debug, PartialEq, Eq, Hash)]
-pub struct Slot {
+/// Pending gates beyond which a recording is run before the next gate is taken: about 28 AES blocks in flight,
+/// 6.5 GB of pool.  Results do not change; gates on either side of the cut stop sharing stages.
+pub const AUTO_FLUSH_GATES: usize = 2_000_000;
+
+/// One pool slot, owned by the handles that name it.  `level` / `epoch`: the stage of the current recording that
+/// writes the slot (0 once the recording that wrote it has been flushed, i.e. when `epoch` is not the key's).
+pub struct SlotRef {
     pub index: u32,
+    level: u32,
+    epoch: u64,
+    released: Arc<Mutex<Vec<u32>>>,
+}
+impl Drop for SlotRef {
+    fn drop(&mut self) {
+        // only the free list's own lock is taken here, never the engine's: a handle may be dropped anywhere
+        if let Ok(mut r) = self.released.lock() {
+            r.push(self.index);
+        }
+    }
+}
+impl std::fmt::Debug for SlotRef {
+    fn fmt(&self, f: &mut std::fmt::Formatter<'_>) -> std::fmt::Result {
+        write!(f, "slot {} (level {}, epoch {})", self.index, self.level, self.epoch)
+    }
+}
+
+#[derive(Clone, Debug)]
+pub struct Slot {
+    pub handle: Arc<SlotRef>,
     pub negated: bool,
+}
+impl Slot {
+    pub fn index(&self) -> u32 {
+        self.handle.index
+    }
 }
 
 #[derive(Clone, Debug)]
@@ -31,11 +74,25 @@ pub enum Op {
     Xnor,
 }
 
+/// What the host side did since the key was made (the counters the C++ mirror reports as `tfh_host_stats`).
+#[derive(Clone, Copy, Debug, Default)]
+pub struct HostStats {
+    pub gates: u64,
+    pub stages: u64,
+    pub flushes: u64,
+    pub max_stage_width: u64,
+}
+
 struct Engine {
     ctx: *mut sys::tfa_ctx,
-    params: sys::tfa_params,
-    next_slot: u32,
+    next_fresh: u32,
     capacity: u32,
+    free: Vec<u32>,                  // slots whose readers have all been submitted
+    released: Arc<Mutex<Vec<u32>>>,  // slots dropped since the last flush: recorded gates may still read them
+    recording: bool,
+    levels: Vec<Vec<sys::tfa_gate>>, // levels[l - 1] = the recorded gates of dependency level l
+    pending_gates: usize,
+    stats: HostStats,
 }
 unsafe impl Send for Engine {}
 
@@ -46,15 +103,42 @@ impl Engine {
             panic!("tfhe-aes-hip error {rc}: {}", msg.to_string_lossy());
         }
     }
-    fn alloc(&mut self, count: u32) -> u32 {
-        let first = self.next_slot;
-        self.next_slot += count;
-        if self.next_slot > self.capacity {
-            self.capacity = (self.next_slot * 2).max(1 << 16);
+    fn alloc(&mut self) -> u32 {
+        if !self.recording {
+            // eager: every earlier reader of a released slot is already on the stream, and the stream is ordered
+            let mut r = self.released.lock().unwrap();
+            self.free.append(&mut r);
+        }
+        if let Some(s) = self.free.pop() {
+            return s;
+        }
+        if self.next_fresh == self.capacity {
+            self.capacity = (self.capacity * 2).max(1 << 17); // 131072 slots: one AES block in flight without a reallocation
             let rc = unsafe { sys::tfa_pool_reserve(self.ctx, self.capacity) };
             self.check(rc);
         }
-        first
+        self.next_fresh += 1;
+        self.next_fresh - 1
+    }
+    /// Runs the recording: one stage per level, then the slots released meanwhile become reusable.
+    fn flush(&mut self, epoch: &AtomicU64) {
+        for lv in self.levels.drain(..).collect::<Vec<_>>() {
+            if lv.is_empty() {
+                continue;
+            }
+            let rc = unsafe { sys::tfa_stage_submit(self.ctx, lv.as_ptr(), lv.len() as u32) };
+            self.check(rc);
+            self.stats.gates += lv.len() as u64;
+            self.stats.stages += 1;
+            self.stats.max_stage_width = self.stats.max_stage_width.max(lv.len() as u64);
+        }
+        let rc = unsafe { sys::tfa_sync(self.ctx) };
+        self.check(rc);
+        self.pending_gates = 0;
+        self.stats.flushes += 1;
+        epoch.fetch_add(1, Ordering::SeqCst);
+        let mut r = self.released.lock().unwrap();
+        self.free.append(&mut r);
     }
 }
 impl Drop for Engine {
@@ -64,10 +148,12 @@ impl Drop for Engine {
 }
 
 /// `tfhe::boolean::ServerKey`: `Clone` and shareable between threads like the original
-/// (primitive.rs:21, `&ServerKey` crossing rayon workers); submissions are serialised on the context.
+/// (primitive.rs:21, `&ServerKey` crossing rayon workers); recording and submission are serialised on the context.
 #[derive(Clone)]
 pub struct ServerKey {
     engine: Arc<Mutex<Engine>>,
+    epoch: Arc<AtomicU64>, // number of flushes: a handle written in an older epoch is complete (level 0)
+    released: Arc<Mutex<Vec<u32>>>,
 }
 
 pub struct ClientKey {
@@ -95,9 +181,13 @@ pub fn gen_keys_on(hip_device: i32, seed: u64) -> (ClientKey, ServerKey) {
         let mut ctx = std::ptr::null_mut();
         let rc = sys::tfa_ctx_create(&p, hip_device, &mut ctx);
         assert_eq!(rc, sys::TFA_OK, "tfa_ctx_create failed: is a gfx950 GPU visible?");
-        let engine = Engine { ctx, params: p, next_slot: 0, capacity: 0 };
+        let released = Arc::new(Mutex::new(Vec::new()));
+        let engine = Engine {
+            ctx, next_fresh: 0, capacity: 0, free: Vec::new(), released: released.clone(), recording: true, levels: Vec::new(), pending_gates: 0,
+            stats: HostStats::default(),
+        };
         engine.check(sys::tfa_keys_upload(ctx, bsk.as_ptr(), ksk.as_ptr()));
-        let server = ServerKey { engine: Arc::new(Mutex::new(engine)) };
+        let server = ServerKey { engine: Arc::new(Mutex::new(engine)), epoch: Arc::new(AtomicU64::new(0)), released };
         (ClientKey { params: p, lwe_sk, server: server.clone(), deterministic: seed != 0, next_seed: Mutex::new(seed.wrapping_mul(0x9E37_79B9_7F4A_7C15)) }, server)
     }
 }
@@ -122,27 +212,29 @@ impl ClientKey {
         let rc = unsafe { sys::tfa_client_encrypt(&self.params, self.lwe_sk.as_ptr(), seed, raw.as_ptr(), bits.len() as u32, lwe.as_mut_ptr()) };
         assert_eq!(rc, sys::TFA_OK);
         let mut e = self.server.engine.lock().unwrap();
-        let first = e.alloc(bits.len() as u32);
-        let slots: Vec<u32> = (first..first + bits.len() as u32).collect();
+        // a slot on the free list has no reader among the recorded gates, so writing it now is safe in both modes
+        let slots: Vec<u32> = (0..bits.len()).map(|_| e.alloc()).collect();
         let rc = unsafe { sys::tfa_pool_write(e.ctx, slots.as_ptr(), slots.len() as u32, lwe.as_ptr()) };
         e.check(rc);
-        slots.into_iter().map(|index| Ciphertext::Encrypted(Slot { index, negated: false })).collect()
+        let epoch = self.server.epoch.load(Ordering::SeqCst);
+        slots.into_iter().map(|index| self.server.handle(index, 0, epoch)).collect()
     }
-    /// `ClientKey::decrypt` (primitive.rs:85): phase < 2^31.
+    /// `ClientKey::decrypt` (primitive.rs:85): phase < 2^31.  Runs whatever is recorded first.
     pub fn decrypt(&self, ct: &Ciphertext) -> bool {
         self.decrypt_many(std::slice::from_ref(ct))[0]
     }
     pub fn decrypt_many(&self, cts: &[Ciphertext]) -> Vec<bool> {
         let n1 = self.params.lwe_dimension as usize + 1;
-        let enc: Vec<(usize, Slot)> = cts.iter().enumerate().filter_map(|(i, c)| if let Ciphertext::Encrypted(s) = c { Some((i, *s)) } else { None }).collect();
+        let enc: Vec<(usize, &Slot)> = cts.iter().enumerate().filter_map(|(i, c)| if let Ciphertext::Encrypted(s) = c { Some((i, s)) } else { None }).collect();
         let mut out: Vec<bool> = cts.iter().map(|c| matches!(c, Ciphertext::Trivial(true))).collect();
         if enc.is_empty() {
             return out;
         }
-        let slots: Vec<u32> = enc.iter().map(|(_, s)| s.index).collect();
+        let slots: Vec<u32> = enc.iter().map(|(_, s)| s.index()).collect();
         let mut lwe = vec![0u32; slots.len() * n1];
         {
-            let e = self.server.engine.lock().unwrap();
+            let mut e = self.server.engine.lock().unwrap();
+            e.flush(&self.server.epoch);
             let rc = unsafe { sys::tfa_pool_read(e.ctx, slots.as_ptr(), slots.len() as u32, lwe.as_mut_ptr()) };
             e.check(rc);
         }
@@ -164,29 +256,50 @@ enum Pending {
     Gate,              // result in the slot reserved for this ticket
 }
 
-/// The gates of ONE stage (no gate may read another's output).  Replaces a rayon `par_iter` over gate calls:
-/// record with `gate`/`mux`, then `run` submits them with a single `tfa_stage_submit`.
+/// A group of gates none of which reads another's output.  Replaces a rayon `par_iter` over gate calls: record
+/// with `gate`/`mux`, then `run`.  On an eager key `run` submits the group as ONE stage; on a recording key it
+/// files every gate at its own dependency level, to be submitted by the next flush.
 pub struct StageBatch<'a> {
     key: &'a ServerKey,
     pending: Vec<Pending>,
     gates: Vec<sys::tfa_gate>, // `out` holds the ticket until `run` assigns slots
+    levels: Vec<u32>,          // per gate: deepest level among its operands, as of the epoch in `epochs`
+    epochs: Vec<u64>,
+    held: Vec<Arc<SlotRef>>,   // operands stay alive until their gate has been filed
 }
 
 impl ServerKey {
+    fn handle(&self, index: u32, level: u32, epoch: u64) -> Ciphertext {
+        Ciphertext::Encrypted(Slot { handle: Arc::new(SlotRef { index, level, epoch, released: self.released.clone() }), negated: false })
+    }
+    /// `true` (default): gates are recorded and run level by level at the next flush / decrypt; `false`: every
+    /// `StageBatch::run` (and every single gate call) submits at once.  Switching runs what is recorded.
+    pub fn set_recording(&self, on: bool) {
+        let mut e = self.engine.lock().unwrap();
+        e.flush(&self.epoch);
+        e.recording = on;
+    }
+    /// Runs the recorded gates, one `tfa_stage_submit` per dependency level, and waits for them.
+    pub fn flush(&self) {
+        self.engine.lock().unwrap().flush(&self.epoch);
+    }
+    pub fn host_stats(&self) -> HostStats {
+        self.engine.lock().unwrap().stats
+    }
     pub fn trivial_encrypt(&self, bit: bool) -> Ciphertext {
         Ciphertext::Trivial(bit)
     }
     pub fn not(&self, ct: &Ciphertext) -> Ciphertext {
         match ct {
             Ciphertext::Trivial(b) => Ciphertext::Trivial(!b),
-            Ciphertext::Encrypted(s) => Ciphertext::Encrypted(Slot { index: s.index, negated: !s.negated }),
+            Ciphertext::Encrypted(s) => Ciphertext::Encrypted(Slot { handle: s.handle.clone(), negated: !s.negated }),
         }
     }
     pub fn not_assign(&self, ct: &mut Ciphertext) {
         *ct = self.not(ct);
     }
     pub fn batch(&self) -> StageBatch<'_> {
-        StageBatch { key: self, pending: Vec::new(), gates: Vec::new() }
+        StageBatch { key: self, pending: Vec::new(), gates: Vec::new(), levels: Vec::new(), epochs: Vec::new(), held: Vec::new() }
     }
     fn single(&self, op: Op, a: &Ciphertext, b: &Ciphertext) -> Ciphertext {
         let mut batch = self.batch();
@@ -225,6 +338,29 @@ impl<'a> StageBatch<'a> {
         self.pending.push(Pending::Ready(ct));
         self.pending.len() - 1
     }
+    fn file(&mut self, code: u32, ins: &[&Slot]) -> Ticket {
+        self.pending.push(Pending::Gate);
+        let ticket = self.pending.len() - 1;
+        let now = self.key.epoch.load(Ordering::SeqCst);
+        let mut g = sys::tfa_gate { op: code, in0: 0, in1: 0, in2: 0, out: ticket as u32, neg: 0 };
+        let mut level = 0;
+        for (k, s) in ins.iter().enumerate() {
+            match k {
+                0 => g.in0 = s.index(),
+                1 => g.in1 = s.index(),
+                _ => g.in2 = s.index(),
+            }
+            g.neg |= (s.negated as u32) << k;
+            if s.handle.epoch == now {
+                level = level.max(s.handle.level);
+            }
+            self.held.push(s.handle.clone());
+        }
+        self.gates.push(g);
+        self.levels.push(level);
+        self.epochs.push(now);
+        ticket
+    }
     /// One two-input gate.  A trivial operand is resolved as tfhe-rs does: and(x,T)=x, and(x,F)=F, or(x,T)=T,
     /// or(x,F)=x, xor(x,T)=not x, xor(x,F)=x, and the negated forms accordingly.
     pub fn gate(&mut self, op: Op, a: &Ciphertext, b: &Ciphertext) -> Ticket {
@@ -247,10 +383,7 @@ impl<'a> StageBatch<'a> {
                     Op::Xor => sys::TFA_XOR,
                     Op::Xnor => sys::TFA_XNOR,
                 };
-                self.pending.push(Pending::Gate);
-                let ticket = self.pending.len() - 1;
-                self.gates.push(sys::tfa_gate { op: code, in0: x.index, in1: y.index, in2: 0, out: ticket as u32, neg: x.negated as u32 | (y.negated as u32) << 1 });
-                ticket
+                self.file(code, &[x, y])
             }
         }
     }
@@ -264,36 +397,49 @@ impl<'a> StageBatch<'a> {
             (_, Trivial(false), _) => { let nc = self.key.not(c); self.gate(Op::And, &nc, e) }
             (_, _, Trivial(true)) => { let nc = self.key.not(c); self.gate(Op::Or, t, &nc) }
             (_, _, Trivial(false)) => self.gate(Op::And, c, t),
-            (Encrypted(s), Encrypted(x), Encrypted(y)) => {
-                self.pending.push(Pending::Gate);
-                let ticket = self.pending.len() - 1;
-                self.gates.push(sys::tfa_gate {
-                    op: sys::TFA_MUX, in0: s.index, in1: x.index, in2: y.index, out: ticket as u32,
-                    neg: s.negated as u32 | (x.negated as u32) << 1 | (y.negated as u32) << 2,
-                });
-                ticket
-            }
+            (Encrypted(s), Encrypted(x), Encrypted(y)) => self.file(sys::TFA_MUX, &[s, x, y]),
         }
     }
-    /// Submits the recorded gates as one stage; result k belongs to ticket k.
-    pub fn run(mut self) -> Vec<Ciphertext> {
-        let mut e = self.key.engine.lock().unwrap();
-        let first = e.alloc(self.gates.len() as u32);
-        let mut slot_of = vec![0u32; self.pending.len()];
-        for (k, g) in self.gates.iter_mut().enumerate() {
-            slot_of[g.out as usize] = first + k as u32;
-            g.out = first + k as u32;
+    /// Result k belongs to ticket k.  Eager key: the gates run now, as one stage.  Recording key: each gate is filed
+    /// at level 1 + (deepest operand level) of the current recording and runs at the next flush.
+    pub fn run(self) -> Vec<Ciphertext> {
+        let StageBatch { key, pending, mut gates, levels, epochs, held } = self;
+        let mut slot_of: Vec<Option<Ciphertext>> = (0..pending.len()).map(|_| None).collect();
+        {
+            let mut e = key.engine.lock().unwrap();
+            if e.recording && e.pending_gates + gates.len() > AUTO_FLUSH_GATES {
+                e.flush(&key.epoch);
+            }
+            let now = key.epoch.load(Ordering::SeqCst);
+            for (k, g) in gates.iter_mut().enumerate() {
+                let ticket = g.out as usize;
+                g.out = e.alloc();
+                // operand levels were read in epoch `epochs[k]`; after a flush in between they are all complete
+                let level = if e.recording { 1 + if epochs[k] == now { levels[k] } else { 0 } } else { 0 };
+                slot_of[ticket] = Some(key.handle(g.out, level, now));
+                if e.recording {
+                    if e.levels.len() < level as usize {
+                        e.levels.resize(level as usize, Vec::new());
+                    }
+                    e.levels[level as usize - 1].push(*g);
+                    e.pending_gates += 1;
+                }
+            }
+            if !e.recording && !gates.is_empty() {
+                let rc = unsafe { sys::tfa_stage_submit(e.ctx, gates.as_ptr(), gates.len() as u32) };
+                e.check(rc);
+                e.stats.gates += gates.len() as u64;
+                e.stats.stages += 1;
+                e.stats.max_stage_width = e.stats.max_stage_width.max(gates.len() as u64);
+            }
         }
-        if !self.gates.is_empty() {
-            let rc = unsafe { sys::tfa_stage_submit(e.ctx, self.gates.as_ptr(), self.gates.len() as u32) };
-            e.check(rc);
-        }
-        self.pending
+        drop(held); // the operands' gates are filed (or on the stream): their slots may be released from here on
+        pending
             .into_iter()
             .enumerate()
             .map(|(k, p)| match p {
                 Pending::Ready(ct) => ct,
-                Pending::Gate => Ciphertext::Encrypted(Slot { index: slot_of[k], negated: false }),
+                Pending::Gate => slot_of[k].take().expect("slot assigned"),
             })
             .collect()
     }
