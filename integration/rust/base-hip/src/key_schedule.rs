@@ -45,7 +45,8 @@ impl Key {
         let rot: [usize; 4] = [7, 11, 15, 3];
         let refs: Vec<&FHEByte> = rot.iter().map(|&i| &self.data[i]).collect();
         let mut temp = eval_circuit(s_box_circuit(), &refs, sk);
-        temp[0].xor_in_place(&FHEByte::from_u8_clear(rcon, sk), sk);
+        let round_constant = FHEByte::from_u8_clear(rcon, sk);
+        temp[0] = bytes_gate(Op::Xor, &[(&temp[0], &round_constant)], sk).pop().unwrap();
         // column c of row r sits at data[4 r + c]: column 0 takes temp, column c + 1 takes the new column c
         let col0: [usize; 4] = [0, 4, 8, 12];
         let pairs: Vec<(&FHEByte, &FHEByte)> = col0.iter().map(|&i| (&self.data[i], &temp[i / 4])).collect();
