@@ -43,6 +43,7 @@ struct tfa_ctx {
     uint32_t *d_ksk = nullptr;
     c64 *d_tw = nullptr;
     int8_t *d_ksk8 = nullptr;  // keyswitching key as signed byte planes for the int8 matrix cores (default parameter shape only)
+    c64 *d_bsk_ls = nullptr;   // TFA_LANESUM: copy of the Fourier key in the lane-local-sum layout of the hand-scheduled wide loops
     c64 *d_bsk_lat = nullptr;  // second copy of the Fourier key in the latency kernel's layout
     c64 *d_tw_lat = nullptr;
     uint32_t ksk_stride = 0;
@@ -270,6 +271,7 @@ extern "C" int tfa_ctx_destroy(tfa_ctx *ctx) {
     hipFree(ctx->d_tw);
     hipFree(ctx->d_ksk8);
     hipFree(ctx->d_bsk_lat);
+    hipFree(ctx->d_bsk_ls);
     hipFree(ctx->d_tw_lat);
     hipFree(ctx->d_pool);
     hipFree(ctx->d_big);
@@ -300,6 +302,10 @@ extern "C" int tfa_keys_upload(tfa_ctx *ctx, const uint32_t *bsk, const uint32_t
         HIPCHK(ctx, hipMalloc(&ctx->d_bsk_f, bsk_words / 2 * sizeof(c64) + kAsmKeySlackBytes));
         HIPCHK(ctx, hipMemset(reinterpret_cast<unsigned char *>(ctx->d_bsk_f) + bsk_words / 2 * sizeof(c64), 0, kAsmKeySlackBytes));
     }
+    if (TFA_LANESUM && !ctx->d_bsk_ls) {
+        HIPCHK(ctx, hipMalloc(&ctx->d_bsk_ls, bsk_words / 2 * sizeof(c64) + kAsmKeySlackBytes));
+        HIPCHK(ctx, hipMemset(reinterpret_cast<unsigned char *>(ctx->d_bsk_ls) + bsk_words / 2 * sizeof(c64), 0, kAsmKeySlackBytes));
+    }
     if (!ctx->d_bsk_lat) {  // plus one step of slack: the hand-scheduled loop loads the key one step ahead without an end-of-key test
         HIPCHK(ctx, hipMalloc(&ctx->d_bsk_lat, bsk_words / 2 * sizeof(c64) + kLatKeySlackBytes));
         HIPCHK(ctx, hipMemset(reinterpret_cast<unsigned char *>(ctx->d_bsk_lat) + bsk_words / 2 * sizeof(c64), 0, kLatKeySlackBytes));
@@ -327,6 +333,11 @@ extern "C" int tfa_keys_upload(tfa_ctx *ctx, const uint32_t *bsk, const uint32_t
         hipLaunchKernelGGL(bsk_convert_kernel, dim3((rows + kConvertWaves - 1) / kConvertWaves), dim3(256), kConvertLdsBytes, ctx->stream, d_std,
                            ctx->d_bsk_f, ctx->d_tw, rows);
         e = hipGetLastError();
+        if (e == hipSuccess && TFA_LANESUM) {
+            const size_t total = (size_t)n * 128 * 64;
+            hipLaunchKernelGGL(bsk_lanesum_layout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_bsk_f, ctx->d_bsk_ls, n);
+            e = hipGetLastError();
+        }
         if (e == hipSuccess) {
             hipLaunchKernelGGL(bsk_convert_lat_kernel, dim3(rows), dim3(256), kLatConvertLdsBytes, ctx->stream, d_std, ctx->d_bsk_lat, ctx->d_tw_lat, rows);
             e = hipGetLastError();
@@ -451,18 +462,19 @@ extern "C" int tfa_pool_device_ptr(tfa_ctx *ctx, void **dptr, uint32_t *stride_w
 // workgroup's four waves with that many workgroups per CU.
 static void launch_variant(tfa_ctx *ctx, int variant, const uint32_t *in_base, uint32_t in_stride, const PbsJob *jobs, uint32_t count, uint32_t steps,
                            uint32_t *big, uint32_t *acc, bool calibration = false) {
+    const c64 *asm_key = TFA_LANESUM ? ctx->d_bsk_ls : ctx->d_bsk_f;  // the hand-scheduled wide loops' key layout
     if (variant == 8 && ctx->pbs_asm && calibration)
         hipLaunchKernelGGL(pbs_asm_kernel<1>, dim3((count + 7) / 8), dim3(512), AsmGeom<8>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
-                           ctx->d_bsk_f, ctx->d_tw, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
+                           asm_key, ctx->d_tw, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
     else if (variant == 8 && ctx->pbs_asm)
         hipLaunchKernelGGL(pbs_asm_kernel<0>, dim3((count + 7) / 8), dim3(512), AsmGeom<8>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
-                           ctx->d_bsk_f, ctx->d_tw, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
+                           asm_key, ctx->d_tw, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
     else if (variant == 8)
         hipLaunchKernelGGL(pbs_kernel<8>, dim3((count + 7) / 8), dim3(512), PbsGeom<8>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
                            ctx->d_bsk_f, ctx->d_tw, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
     else if (variant == 4 && ctx->pbs_asm)
         hipLaunchKernelGGL((pbs_asm_kernel<0, 4>), dim3((count + 3) / 4), dim3(256), AsmGeom<4>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
-                           ctx->d_bsk_f, ctx->d_tw, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
+                           asm_key, ctx->d_tw, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);
     else if (variant == 4)
         hipLaunchKernelGGL(pbs_kernel<4>, dim3((count + 3) / 4), dim3(256), PbsGeom<4>::kLdsBytes, ctx->stream, in_base, in_stride, jobs, count,
                            ctx->d_bsk_f, ctx->d_tw, ctx->p.lwe_dimension, steps, big, ctx->big_stride, acc);

@@ -8,6 +8,7 @@ for v in "$@"; do
   n=${v%%=*}; f=${v#*=}
   PBS_ASM_OPT=$f python3 tools/pbs_asm/gen.py tools/exp/loop_$n.inc > /dev/null
   (PBS_ASM_OPT=$f python3 tools/pbs_asm/emu.py 1 | grep -q "mismatching words 0" || { echo "variant $n fails on the emulator"; exit 1; }
-   tools/build_exp.sh asm_$n "-DTFA_PBS_ASM_INC=\"../../tools/exp/loop_$n.inc\"" 2>&1 | grep -iE "error" || true) &
+   ls=1; [[ -n "$f" && ",$f," != *,lanesum,* ]] && ls=0      # the key layout and twiddle table follow the loop's "lanesum" option
+   tools/build_exp.sh asm_$n "-DTFA_LANESUM=$ls -DTFA_PBS_ASM_INC=\"../../tools/exp/loop_$n.inc\"" 2>&1 | grep -iE "error" || true) &
 done
 wait

@@ -158,6 +158,44 @@ CASES = [
     ("mix fma f64 + bfe (1:1)", [x for pair in zip(fma_acc(16, 2, 0, 0, 2)[:32], rep("v_bfe_i32 {d}, {a}, {m}, 1")[:32]) for x in pair]),
 ]
 
+
+
+def bank_cases():
+    """Every placement of the operands of the loop's four fp64 forms over the register classes r % 4 = 0 and r % 4 = 2
+    (64-bit operands are even-aligned).  Sources are read-only registers, a different one per instruction, and
+    destinations rotate over 8 registers, so nothing depends on anything (except the in-place forms, 8 apart)."""
+    src_pool = {0: [SRC0 + 4 * j for j in range(4)], 2: [SRC0 + 4 * j + 2 for j in range(4)]}      # v96-111
+    dst_pool = {0: [ACC0 + 4 * j for j in range(8)], 2: [ACC0 + 4 * j + 2 for j in range(8)]}      # v32-63
+    out = []
+
+    def body(fmt, dm, mods, inplace):
+        lines = []
+        for i in range(64):
+            dreg_ = dst_pool[dm][i % 8]
+            ops = [d(src_pool[m][(i + 3 * k) % 4]) for k, m in enumerate(mods)]
+            if inplace:
+                ops[-1] = d(dreg_)
+            lines.append(fmt % tuple([d(dreg_)] + ops))
+        return lines
+    for dm in (0, 2):
+        for am in (0, 2):
+            for bm in (0, 2):
+                out.append(("add  d%d a%d b%d" % (dm, am, bm), body("v_add_f64 %s, %s, %s", dm, (am, bm), False)))
+                out.append(("mul  d%d a%d b%d" % (dm, am, bm), body("v_mul_f64 %s, %s, %s", dm, (am, bm), False)))
+                out.append(("fmas d%d a%d c%d (b sgpr)" % (dm, am, bm), body("v_fma_f64 %s, %s, s[20:21], %s", dm, (am, bm), False)))
+                for cm in (0, 2):
+                    out.append(("fma  d%d a%d b%d c%d" % (dm, am, bm, cm), body("v_fma_f64 %s, %s, %s, %s", dm, (am, bm, cm), False)))
+            out.append(("add  d%d += a%d (in place)" % (dm, am), body("v_add_f64 %s, %s, %s", dm, (am, dm), True)))
+            out.append(("fmas d%d += a%d * sgpr" % (dm, am), body("v_fma_f64 %s, %s, s[20:21], %s", dm, (am, dm), True)))
+            for bm in (0, 2):
+                out.append(("fma  d%d += a%d * b%d" % (dm, am, bm), body("v_fma_f64 %s, %s, %s, %s", dm, (am, bm, dm), True)))
+    return out
+
+
+import sys
+MODE = sys.argv[1] if len(sys.argv) > 1 else "ops"
+if MODE == "banks":
+    CASES = bank_cases()
 src = ['// GENERATED by tools/gen_probe_banks.py', '#include <hip/hip_runtime.h>', '#include <cstdio>',
        '#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)']
 clob = ", ".join('"v%d"' % r for r in list(range(ACC0, ACC0 + 64)) + list(range(SRC0, SRC0 + 16)))
@@ -188,7 +226,7 @@ for n, (label, body) in enumerate(CASES):
     src.append('    {"%s", k%d},' % (label, n))
 src.append('  };')
 src.append('  const int iters = 20000;')
-src.append('  for (int rep = 0; rep < 2; rep++) for (int wps = 4; wps >= 1; wps--) {')
+src.append('  for (int rep = 0; rep < %d; rep++) for (int wps = %d; wps >= %d; wps--) {' % ((3, 2, 2) if MODE == 'banks' else (2, 4, 1)) + '')
 src.append('   printf("---- %d wave(s) per SIMD: cycles per instruction and SIMD (cycle counter | wall clock at 2.4 GHz)\\n", wps);')
 src.append('   for (auto& e : ks) {')
 src.append('    hipLaunchKernelGGL(e.k, dim3(256), dim3(256 * wps), 0, 0, dv, 10);')
@@ -203,4 +241,4 @@ src.append('   }')
 src.append('  }')
 src.append('  return 0;')
 src.append('}')
-open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "probe_banks.hip"), "w").write("\n".join(src) + "\n")
+open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "probe_banks2.hip" if MODE == "banks" else "probe_banks.hip"), "w").write("\n".join(src) + "\n")

@@ -278,9 +278,33 @@ class Machine:
                 raise NotImplementedError(ln)
 
 
+def fourier_key_lanesum(bsk, n_steps):
+    """Fourier key in the layout of the lane-local sum: [i][k_lo][level][j][j'][lane] c64, lane = 4 k1 + x: the word that
+    multiplies slot set j (polynomial (x - j) & 3) into output slot j' (column (x - j') & 3) at bin k1 + 16 (k_lo + 4 x)."""
+    out = np.zeros((n_steps + 1, 4, 2, 4, 4, 64), np.complex128)
+    b = bsk.reshape(-1, 2, 4, 4, 512).view(np.int32).astype(np.float64)
+    tw = np.exp(1j * np.pi * np.arange(256) / 512)
+    for i in range(n_steps):
+        for lv in range(2):
+            F = np.zeros((4, 4, 256), np.complex128)
+            for r in range(4):
+                for c in range(4):
+                    p = b[i, lv, r, c]
+                    F[r, c] = np.fft.ifft((p[:256] + 1j * p[256:]) * tw)
+            for k_lo in range(4):
+                for j in range(4):
+                    for jp in range(4):
+                        for k1 in range(16):
+                            for x in range(4):
+                                out[i, k_lo, lv, j, jp, 4 * k1 + x] = F[(x - j) & 3, (x - jp) & 3, k1 + 16 * (k_lo + 4 * x)]
+    return out.view(np.float64).reshape(-1).view(np.uint8)
+
+
 def fourier_key(bsk, n_steps):
     """Fourier key of the first n_steps mask elements in the kernel's layout [i][level][p][slot][lane] c64 (the layout
     bsk_convert_kernel of pbs_kernel.h produces), padded by a step for the ring's prefetch."""
+    if G.LANESUM:
+        return fourier_key_lanesum(bsk, n_steps)
     out = np.zeros((n_steps + 1, 2, 16, 4, 64), np.complex128)
     b = bsk.reshape(-1, 2, 4, 4, 512).view(np.int32).astype(np.float64)
     j = np.arange(256)
@@ -318,7 +342,9 @@ def main():
         for q in range(4):
             M.v[G.V_TRWR[q]][w] = wl + 8 * (g * G.K_TR_GROUP + (t ^ (2 * q)))
             M.v[G.V_TRRD[q]][w] = wl + 8 * (g * G.K_TR_GROUP + t * 16) + 16 * (q ^ (t >> 2))
-        M.v[G.V_TW][w] = G.K_TW_OFFSET + t * 16
+        M.v[G.V_TW][w] = G.K_TW_OFFSET + t * (64 if G.LANESUM else 16)
+        if G.LANESUM:     # rotation q of an entry sits at byte 16 q
+            M.v[G.V_TWF][w] = G.K_TW_OFFSET + t * 64 + 16 * ((g * t) & 3)
         M.v[G.V_LANE16][w] = lane * 16
         M.v[G.V_KBASE][w] = lane * 16
         b_tilde = int(a_tilde[w, n])
@@ -336,7 +362,7 @@ def main():
         M.lds[al: al + 2 * at.size] = at.view(np.uint8)
         rpw = G.ROWS_PER_WAVE
         r0 = rpw * w                           # this wave's first DMA row of a chunk: row = (position >> 1) << 3 | level << 2 | column
-        kw = ((r0 >> 2) & 1) * 65536 + (r0 >> 3) * 4096 + (r0 & 3) * 1024
+        kw = r0 * 1024 if G.LANESUM else ((r0 >> 2) & 1) * 65536 + (r0 >> 3) * 4096 + (r0 & 3) * 1024
         M.s[G.S_KP][w] = kw
         M.s[G.S_KP + 1][w] = 0
         M.s[G.S_STEPS][w] = steps
@@ -346,14 +372,22 @@ def main():
         # chunks 0, 1, 2 of step 0 are already on their way when the loop starts
         for ch in range(3):
             for row in range(r0, r0 + rpw):
-                src = kw + ch * 8192 + (row - r0) * 1024
+                src = kw + ch * (G.K_CHUNK_BYTES if G.LANESUM else 8192) + (row - r0) * 1024
                 dst = G.K_RING_OFFSET + ch * G.K_CHUNK_BYTES + row * 1024
                 M.lds[dst:dst + 1024] = key[src:src + 1024]
-    twt = np.zeros((16, 16), np.complex128)
-    for r in range(16):
-        for tt in range(16):
-            twt[r, tt] = np.exp(1j * np.pi * tt * (1 + 4 * r) / 512)
-    M.lds[G.K_TW_OFFSET:G.K_TW_OFFSET + 4096] = twt.view(np.float64).reshape(-1).view(np.uint8)
+    if G.LANESUM:
+        twt = np.zeros((16, 16, 4), np.complex128)
+        for r in range(16):
+            for tt in range(16):
+                for q in range(4):
+                    twt[r, tt, q] = np.exp(1j * np.pi * tt * (1 + 4 * r) / 512) * (1j ** q)
+        M.lds[G.K_TW_OFFSET:G.K_TW_OFFSET + 16384] = twt.view(np.float64).reshape(-1).view(np.uint8)
+    else:
+        twt = np.zeros((16, 16), np.complex128)
+        for r in range(16):
+            for tt in range(16):
+                twt[r, tt] = np.exp(1j * np.pi * tt * (1 + 4 * r) / 512)
+        M.lds[G.K_TW_OFFSET:G.K_TW_OFFSET + 4096] = twt.view(np.float64).reshape(-1).view(np.uint8)
 
     lines = [ln.replace("%=", "") for ln in G.Loop().build()]
     M.run(lines)
@@ -367,7 +401,7 @@ def main():
         bad += int(diff)
         if diff:
             d = (got.astype(np.int64) - ref.astype(np.int64) + 2**31) % 2**32 - 2**31
-            print(f"bootstrap {w}: {diff} of 2048 words differ, max |diff| {np.abs(d).max()}")
+            print(f"bootstrap {w}: {diff} of 2048 words differ, max |diff| {np.abs(d).max()}; per polynomial {[int((got[q] != ref[q]).sum()) for q in range(4)]}")
     print("steps", steps, "mismatching words", bad)
     print({k: v for k, v in sorted(M.count.items())})
     return 1 if bad else 0

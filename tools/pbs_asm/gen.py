@@ -26,8 +26,17 @@ K_A_BYTES = 1664
 WAVES = int(os.environ.get("PBS_ASM_WAVES", "8"))     # bootstraps per workgroup: 8 (two waves per SIMD) or 4 (one per SIMD, for 1024-wide stages)
 assert WAVES in (4, 8)
 ROWS_PER_WAVE = 16 // WAVES                          # LDS-DMA rows of a key chunk each wave fetches
+# schedule choices that can be switched off for measurement (PBS_ASM_OPT=comma list replaces the default set)
+OPT = set(f for f in os.environ.get("PBS_ASM_OPT", "mac_il,tw_spread,inv_split,lanesum,ls_pf2").split(",") if f)
+# "lanesum": the sum over the four polynomials stays inside a lane.  After the second forward pass the four lanes of a quad
+# exchange frequency groups (in-place DPP moves) so that lane x holds, for ALL four polynomials and both levels, the four bins
+# whose high index digit is x; the products then accumulate in registers (no reduce-scatter of partial sums: 48 DPP moves and
+# 96 additions fewer per step), and a second exchange hands output column c to the lanes of polynomial c.  A lane's second-pass
+# transform must deliver its bins rotated by its polynomial number for that: the rotation is a factor i^(g t) on the inputs,
+# folded into the inter-pass twiddles, which the table therefore holds in all four quarter-turn rotations.
+LANESUM = "lanesum" in OPT
 K_TW_OFFSET = WAVES * (K_WAVE_LDS + K_A_BYTES)   # [exchange / rotation buffers][a_tilde arrays][twiddles][key ring]
-K_TW_ROW_BYTES = 256       # twiddle table [element][t], 16 bytes each
+K_TW_ROW_BYTES = 1024 if LANESUM else 256       # twiddle table [element][t]: 16 bytes each, or 4 rotations x 16 bytes
 K_RING_OFFSET = K_TW_OFFSET + 16 * K_TW_ROW_BYTES
 K_CHUNK_BYTES = 16384
 K_LDS_BYTES = K_RING_OFFSET + 4 * K_CHUNK_BYTES
@@ -63,14 +72,14 @@ V_TRWR = [4, 5, 6, 7]            # exchange store address for element groups r >
 V_TRRD = [8, 9, 10, 11]          # exchange row-read address for words (w & 3), offset 64 * (w >> 2)
 V_KBASE = 12                     # LDS base + lane * 16: key words are read at v12 + ring offset
 V_TW, V_LANE16, V_KADDR = 16, 17, 18
+V_TWF = 13                       # lanesum: twiddle row address with this lane's rotation (g t) & 3 added (both directions:
+                                 # the inverse multiplies after its exchange, in the lane whose t is the rotated index)
 V_AREAD = 19                     # next step's rotation amount (u16 read from LDS)
-V_SCR = list(range(20, 32))      # scratch ints; also v[20:21], v[22:23] as fp64 scratch of the twiddle products
+V_SCR = list(range(20, 30))      # scratch ints; also v[20:21], v[22:23] as fp64 scratch of the twiddle products
 V_MAGIC = 30                     # v[30:31] = 1.5 * 2^52
 V_ACC = 32
 R_A, R_B, R_K, R_T = 64, 128, 192, 224
 
-# schedule choices that can be switched off for measurement (PBS_ASM_OPT=comma list replaces the default set)
-OPT = set(f for f in os.environ.get("PBS_ASM_OPT", "mac_il,tw_spread,inv_split").split(",") if f)
 AUTO_WAITS = os.environ.get("PBS_ASM_MANUAL_WAITS", "") == ""   # waits and DPP wait states placed by place_waits()
 
 INLINE = {1.0: "1.0", 0.5: "0.5", 2.0: "2.0", 4.0: "4.0"}
@@ -264,6 +273,11 @@ class Arr:
         r, i = self.slot(self.pos[k])
         return C(V(r), V(i))
 
+    def val_at(self, p):
+        """the value in position p, whatever logical element that is"""
+        r, i = self.slot(p)
+        return C(V(r), V(i))
+
 
 class Loop:
     def __init__(self):
@@ -346,9 +360,27 @@ class Loop:
         e("v_xnor_b32 v%d, v%d, v%d" % (fs, fw, fs))                      # bit m set: sign = +1, the negated n[src] enters
         e("v_and_b32 v%d, 0x1ff, v%d" % (tmp, tmp))
         e("v_lshl_add_u32 v%d, v%d, 4, v%d" % (a0, tmp, V_ROTBASE))    # buffer word 4 index + g
+        fast = "int_fast" in OPT
+        if fast:
+            # Kept for the record, not in the default set.  Alone in a loop, v_add / v_sub / v_and / v_xor / v_lshrrev issue in
+            # about 2.4 cycles at two waves per SIMD and every three-operand integer form (v_bfe, v_add3, v_xad, v_lshl_add)
+            # in about 4.9, like an fp64 instruction; this variant trades each long form for two or three short ones
+            # (97 instructions more per step).  Inside this loop it is 1.3 % SLOWER (215.2 k against 218.0 k bootstraps/s in
+            # one GPU call): between fp64 instructions a short form costs a full issue slot, so only the count matters.
+            w13, whi = V_SCR[4], V_SCR[5]
+            e("v_lshlrev_b32 v%d, 13, v%d" % (w13, fw))                   # bit 13 + m = wrapped(m), m <= 18
+            e("v_lshrrev_b32 v%d, 6, v%d" % (whi, fw))                    # bit 13 + (m - 19) = wrapped(m), m >= 19
         for m in range(32):
-            e("v_bfe_i32 v%d, v%d, %d, 1" % (tmp, fw, m))
-            e("v_lshl_add_u32 v%d, v%d, 13, v%d" % (tmp, tmp, a0))      # a0 - 8192 once wrapped
+            if fast:
+                if m == 0:
+                    e("v_and_b32 v%d, 0x2000, v%d" % (tmp, w13))
+                else:
+                    e("v_lshrrev_b32 v%d, %d, v%d" % (tmp, m if m <= 18 else m - 19, w13 if m <= 18 else whi))
+                    e("v_and_b32 v%d, 0x2000, v%d" % (tmp, tmp))
+                e("v_sub_u32 v%d, v%d, v%d" % (tmp, a0, tmp))               # a0 - 8192 once wrapped
+            else:
+                e("v_bfe_i32 v%d, v%d, %d, 1" % (tmp, fw, m))
+                e("v_lshl_add_u32 v%d, v%d, 13, v%d" % (tmp, tmp, a0))      # a0 - 8192 once wrapped
             e("ds_read_b32 v%d, v%d offset:%d" % (R_K + m, tmp, 256 * m))
         # the m-th read has returned when at most 31 - m younger ones are in flight (the counter saturates at 15)
         sg, c, y, s_, u, w = V_SCR[3], V_SCR[4], V_SCR[5], V_SCR[6], V_SCR[7], V_SCR[8]
@@ -357,12 +389,22 @@ class Loop:
             v = R_K + m
             # y = sign * acc[src] - acc + 2^11 = (n[src] ^ sg) - sg + n + 2^11 with sg = ~0 where sign = +1
             e("v_bfe_i32 v%d, v%d, %d, 1" % (sg, fs, m))
-            e("v_bfe_u32 v%d, v%d, %d, 1" % (c, fs, m))
-            e("v_add3_u32 v%d, v%d, v%d, s%d" % (c, c, V_ACC + m, S_C2048))
-            e("v_xad_u32 v%d, v%d, v%d, v%d" % (y, v, sg, c))
-            e("v_lshrrev_b32 v%d, 12, v%d" % (s_, y))
-            e("v_lshrrev_b32 v%d, 31, v%d" % (u, y))
-            e("v_add3_u32 v%d, v%d, v%d, s%d" % (u, s_, u, S_C511))      # s + bit 19 of the state + 511
+            if fast:
+                e("v_xor_b32 v%d, v%d, v%d" % (y, v, sg))
+                e("v_sub_u32 v%d, v%d, v%d" % (y, y, sg))
+                e("v_add_u32 v%d, v%d, v%d" % (y, y, V_ACC + m))
+                e("v_add_u32 v%d, 0x800, v%d" % (y, y))
+                e("v_lshrrev_b32 v%d, 12, v%d" % (s_, y))
+                e("v_lshrrev_b32 v%d, 31, v%d" % (u, y))
+                e("v_add_u32 v%d, v%d, v%d" % (u, s_, u))
+                e("v_add_u32 v%d, 0x1ff, v%d" % (u, u))                     # s + bit 19 of the state + 511
+            else:
+                e("v_bfe_u32 v%d, v%d, %d, 1" % (c, fs, m))
+                e("v_add3_u32 v%d, v%d, v%d, s%d" % (c, c, V_ACC + m, S_C2048))
+                e("v_xad_u32 v%d, v%d, v%d, v%d" % (y, v, sg, c))
+                e("v_lshrrev_b32 v%d, 12, v%d" % (s_, y))
+                e("v_lshrrev_b32 v%d, 31, v%d" % (u, y))
+                e("v_add3_u32 v%d, v%d, v%d, s%d" % (u, s_, u, S_C511))      # s + bit 19 of the state + 511
             # -d1: the top digit is the value in [-511, 512] congruent to u >> 10 mod 1024, so its negative is the
             # sign-extended 10-bit field of (1023 - u) >> 10 = -(u >> 10); array A carries the sign to the products
             e("v_sub_u32 v%d, 0x3ff, v%d" % (w, u))
@@ -375,7 +417,8 @@ class Loop:
     # ---- twiddles -------------------------------------------------------------------------------------------------------
     def tw_issue(self, k0, count, region):
         for k in range(count):
-            self.e("ds_read_b128 %s, v%d offset:%d" % (qreg(region + 4 * k), V_TW, (k0 + k) * K_TW_ROW_BYTES))
+            addr = V_TWF if LANESUM else V_TW
+            self.e("ds_read_b128 %s, v%d offset:%d" % (qreg(region + 4 * k), addr, (k0 + k) * K_TW_ROW_BYTES))
 
     def tw_mul(self, X, k0, count, region, S):
         """X[k0 .. k0+count) *= (c + i S s) in place, entry j of `region` = (c, s) of element k0 + j"""
@@ -430,7 +473,10 @@ class Loop:
         e("s_waitcnt vmcnt(%d)" % (2 * ROWS_PER_WAVE))       # own rows of chunk q: at most the two younger chunks' rows stay in flight
         e("s_barrier")
         qq = q + 3
-        off = qq * 8192 if qq < 8 else STEP_KEY_BYTES + (qq - 8) * 8192
+        if LANESUM:      # the key is stored in the order the ring takes it: [step][chunk][row][lane]
+            off = qq * K_CHUNK_BYTES if qq < 8 else STEP_KEY_BYTES + (qq - 8) * K_CHUNK_BYTES
+        else:
+            off = qq * 8192 if qq < 8 else STEP_KEY_BYTES + (qq - 8) * 8192
         slot = qq % 4
         for j in range(ROWS_PER_WAVE):
             if j == 0:
@@ -515,6 +561,73 @@ class Loop:
             else:
                 self.out.extend(prod[0] + nxt0 + prod[1] + nxt1 + red)
 
+    # ---- lanesum: quad exchanges and the in-lane multiply-accumulate ---------------------------------------------------------
+    def quad_exchange(self, X, forward):
+        """In place.  forward: lane x takes, from lane (x + d) & 3, the positions of slot set (4 - d) & 3; afterwards slot set j
+        of lane x holds polynomial (x - j) & 3 at the bins with high digit x.  inverse: lane c takes slot set d from lane
+        (c + d) & 3: output column c, bins with high digit (c + d) & 3, in slot set d.  Slot set j = positions j, 4 + j, 8 + j, 12 + j."""
+        for d in (1, 2, 3):
+            j = (4 - d) & 3 if forward else d
+            ctrl = "[%d,%d,%d,%d]" % tuple((i + d) & 3 for i in range(4))
+            for k_lo in range(4):
+                re, im = X.slot(4 * k_lo + j)
+                for reg in (re, re + 1, im, im + 1):
+                    self.e("v_mov_b32_dpp v%d, v%d quad_perm:%s row_mask:0xf bank_mask:0xf" % (reg, reg, ctrl))
+
+    def key_buffers(self):
+        """register blocks of four key words: two in the key region, a third in the half of the temporaries the products
+        leave free (it is loaded only after the last forward butterfly has returned its temporaries)"""
+        return [R_K, R_K + 16, R_T + 16] if "ls_pf2" in OPT else [R_K, R_K + 16]
+
+    def key_issue_ls(self, lv, j, buf):
+        """key words [j][j' = 0..3] of the chunk (k_lo, lv) at hand, into key buffer `buf`"""
+        for jp in range(4):
+            self.e("ds_read_b128 %s, v%d offset:%d" % (qreg(buf + 4 * jp), V_KADDR, (4 * j + jp) * 1024))
+
+    def mac_lanesum(self, A, B):
+        """A[position (k_lo, j')] <- sum over levels and slot sets j of spectrum[lv][(k_lo, j)] x key[k_lo][lv][j][j'].  Eight
+        independent accumulation chains per bin (four output slots, real and imaginary), sixteen multiply-adds each; a term's
+        four key words are fetched one (two with ls_pf2) terms ahead, under the products.  Chunk (k_lo, lv) of the ring = the
+        sixteen key words [j][j'] of one level of one bin."""
+        T = [R_T + 2 * n for n in range(8)]
+        pr, pi = T[0:4], T[4:8]
+        bufs = self.key_buffers()
+        ahead = len(bufs) - 1
+        terms = [(k_lo, lv, j) for k_lo in range(4) for lv in (0, 1) for j in range(4)]
+        # chunk 0 was acquired and the first `ahead` terms' words requested inside the second forward pass (see step())
+        for n, (k_lo, lv, j) in enumerate(terms):
+            X = A if lv == 0 else B
+            f = X.val_at(4 * k_lo + j)
+            if lv == 0:
+                f = C(-f.r, -f.i)                 # array A is the spectrum of the NEGATED level-1 digits
+            first, last = (lv, j) == (0, 0), (lv, j) == (1, 3)
+            buf = bufs[n % len(bufs)]
+            key = [(V(buf + 4 * jp), V(buf + 4 * jp + 2)) for jp in range(4)]
+            ins = []
+            for part in (0, 1):                   # part 0: products with the real part of the spectrum, part 1: imaginary
+                for jp in range(4):
+                    x, y = key[jp]
+                    orr, oi = A.slot(4 * k_lo + jp)
+                    dr = dreg(orr) if (last and part == 1) else dreg(pr[jp])
+                    di = dreg(oi) if (last and part == 1) else dreg(pi[jp])
+                    if first and part == 0:
+                        ins.append("v_mul_f64 %s, %s, %s" % (dreg(pr[jp]), f.r.s(), x.s()))
+                        ins.append("v_mul_f64 %s, %s, %s" % (dreg(pi[jp]), f.r.s(), y.s()))
+                    elif part == 0:
+                        ins.append("v_fma_f64 %s, %s, %s, %s" % (dreg(pr[jp]), f.r.s(), x.s(), dreg(pr[jp])))
+                        ins.append("v_fma_f64 %s, %s, %s, %s" % (dreg(pi[jp]), f.r.s(), y.s(), dreg(pi[jp])))
+                    else:
+                        ins.append("v_fma_f64 %s, %s, %s, %s" % (dr, f.i.s(flip=True), y.s(), dreg(pr[jp])))
+                        ins.append("v_fma_f64 %s, %s, %s, %s" % (di, f.i.s(), x.s(), dreg(pi[jp])))
+            # the key words of the term `ahead` terms on travel under this term's products; a new chunk is acquired first
+            nxt = []
+            if n + ahead < len(terms):
+                nk, nlv, nj = terms[n + ahead]
+                if nj == 0:
+                    nxt += self.capture(self.acquire, 2 * nk + nlv)
+                nxt += self.capture(self.key_issue_ls, nlv, nj, bufs[(n + ahead) % len(bufs)])
+            self.out.extend(self.spread(ins, nxt) if "mac_il" in OPT else ins + nxt)
+
     # ---- the step ---------------------------------------------------------------------------------------------------------
     def capture(self, fn, *args):
         """the lines fn emits, as a list (not appended to the output)"""
@@ -571,12 +684,25 @@ class Loop:
         self.out.extend(self.spread(self.capture(self.tw_mul, B, 0, 8, R_K, 1), self.capture(self.tw_issue, 8, 8, R_T), 0, 32 if "tw_spread" in OPT else 0))
         self.tw_mul(B, 8, 8, R_T, 1)
         # level 2's exchange, the first chunk's barrier and the first key words travel inside the second pass of level 1
-        side = self.capture(self.exchange, B) + self.capture(self.acquire, 0) + self.capture(self.key_issue, 0, 0) + self.capture(self.key_issue, 0, 1)
-        main = self.capture(self.dft16, A, 1, False)
-        self.out.extend(self.spread(main, side))
-        self.dft16(B, 1, False)
-        # spectrum x key
-        self.mac(A, B, prefetched=True)
+        if LANESUM:
+            side = self.capture(self.exchange, B) + self.capture(self.acquire, 0) + self.capture(self.key_issue_ls, 0, 0, R_K)
+            if len(self.key_buffers()) == 3:
+                side += self.capture(self.key_issue_ls, 0, 1, R_K + 16)
+            main = self.capture(self.dft16, A, 1, False)
+            self.out.extend(self.spread(main, side))
+            # level 1's quad exchange travels inside the second pass of level 2
+            main = self.capture(self.dft16, B, 1, False)
+            self.out.extend(self.spread(main, self.capture(self.quad_exchange, A, True)))
+            self.quad_exchange(B, True)
+            self.mac_lanesum(A, B)
+            self.quad_exchange(A, False)
+        else:
+            side = self.capture(self.exchange, B) + self.capture(self.acquire, 0) + self.capture(self.key_issue, 0, 0) + self.capture(self.key_issue, 0, 1)
+            main = self.capture(self.dft16, A, 1, False)
+            self.out.extend(self.spread(main, side))
+            self.dft16(B, 1, False)
+            # spectrum x key
+            self.mac(A, B, prefetched=True)
         # inverse transform of the sums (array A); array B is free and holds all sixteen twiddles
         e("v_mov_b32 v%d, s%d" % (V_SCR[0], S_ACUR))
         e("ds_read_u16 v%d, v%d" % (V_AREAD, V_SCR[0]))
@@ -767,7 +893,7 @@ def main():
     if flags:
         lines = experiment_filter(lines, flags)
     v, s = clobbers(lines)
-    inputs_v = set([V_ROTBASE, V_T] + V_TRWR + V_TRRD + [V_KBASE, V_TW, V_LANE16]) | set(range(V_ACC, V_ACC + 32))
+    inputs_v = set([V_ROTBASE, V_T] + V_TRWR + V_TRRD + [V_KBASE, V_TW, V_LANE16] + ([V_TWF] if LANESUM else [])) | set(range(V_ACC, V_ACC + 32))
     inputs_s = set([S_KP, S_KP + 1, S_STEPS, S_ACUR, S_A, S_M0ROW])
     assert 0 not in v and not (set(range(0, 8)) & set(s)), "v0 / s0-s7 belong to the compiler"
     cl = ['"v%d"' % r for r in v if r not in inputs_v] + ['"s%d"' % r for r in s if r not in inputs_s]
