@@ -1,6 +1,7 @@
 """Reduces the rocprofv3 --pmc passes of tools/profile_round.sh to mean counter values per dispatch and kernel.
-usage: python3 tools/pmc_summary.py gpurun_out/prof_<tag> > summary.json"""
-import csv, glob, json, os, sys
+usage: python3 tools/pmc_summary.py gpurun_out/prof_<tag> [commit] > summary.json   (commit: the revision the profiled library was
+built from; default: HEAD of the repository this script sits in)"""
+import csv, glob, json, os, subprocess, sys
 root = sys.argv[1]
 bootstraps = {"fetch": 65536, "write": 65536, "sq_a": 8192, "sq_b": 8192}
 out = {}
@@ -52,7 +53,7 @@ res = {"note": "rocprofv3 --pmc, separate passes (tools/profile_round.sh), reduc
                "workload's launches (the round-time calibration's launches are left out). FETCH_SIZE/WRITE_SIZE in KiB as reported "
                "(gfx950: double FETCH_SIZE for 16-byte-per-lane reads). @N = bootstraps per dispatch (tools/prof_pbs.py N). "
                "SQ_* wave counters in quad-cycles. The one-bootstrap-per-workgroup kernels (pbs_lat_*) are launched here only by the "
-               "round-time calibration (one round of workgroups, 100 and 300 steps), so only their ratios are meaningful.",
+               "round-time calibration (one round of workgroups, a quarter and three quarters of the steps), so only their ratios are meaningful.",
        "counters_current_kernels": out}
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "pbs_asm"))
 for k, c in out.items():
@@ -69,4 +70,10 @@ for k, c in out.items():
             res["derived_pbs_lat_asm_kernel_2"] = derived(c, 4, ratios_only=True)
     except KeyError:
         pass
+try:
+    res["commit"] = sys.argv[2] if len(sys.argv) > 2 else subprocess.check_output(
+        ["git", "-C", os.path.dirname(os.path.abspath(__file__)), "rev-parse", "HEAD"], text=True).strip()
+except (OSError, subprocess.CalledProcessError):
+    res["commit"] = None
+res["kernel"] = next((k for k in out if "pbs_asm_kernel<0, 8>" in k or "pbs_asm_kernel<0>" in k), None)
 print(json.dumps(res, indent=1, sort_keys=True))

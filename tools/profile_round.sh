@@ -9,6 +9,7 @@ mkdir -p $out
 export TMPDIR=/tmp
 echo "[kt noaes]"; timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $out/kt_noaes --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-aes > $out/kt_noaes.log 2>&1
 echo "[kt full]";  timeout -s KILL 400 rocprofv3 --kernel-trace --stats -d $out/kt_full --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/kt_full.log 2>&1
+echo "[kt aes block]"; timeout -s KILL 200 rocprofv3 --kernel-trace -d $out/kt_aes --output-format csv -- python3 tools/aes_trace.py > $out/kt_aes.log 2>&1
 pass() {  # name bootstraps counters...
   local name=$1 n=$2; shift 2
   echo "[pmc $name]"; timeout -s KILL 120 rocprofv3 --pmc "$@" -d $out/pmc_$name --output-format csv -- python3 tools/prof_pbs.py $n > $out/pmc_$name.log 2>&1
