@@ -243,6 +243,17 @@ class Machine:
                 by = np.stack([(words >> np.uint32(8 * j)) & np.uint32(0xFF) for j in range(4)], axis=-1).astype(np.uint8)
                 self.lds_write(addr, by.reshape(W, L, n))
                 self.lds_queue.append(None)
+            elif op == "ds_write2_b64":
+                addr_tok = a[0]
+                o0, o1 = int(re.search(r"offset0:(\d+)", rest).group(1)), int(re.search(r"offset1:(\d+)", rest).group(1))
+                datas = [int(re.match(r"v\[(\d+)", a[1]).group(1)), int(re.match(r"v\[(\d+)", a[2].split()[0]).group(1))]
+                for off, r0 in zip((o0, o1), datas):
+                    addr = self.src32(addr_tok) + np.uint32(8 * off)
+                    assert (addr % 8 == 0).all(), "misaligned LDS write"
+                    words = np.stack([self.v[r0], self.v[r0 + 1]], axis=-1)
+                    by = np.stack([(words >> np.uint32(8 * j)) & np.uint32(0xFF) for j in range(4)], axis=-1).astype(np.uint8)
+                    self.lds_write(addr, by.reshape(W, L, 8))
+                self.lds_queue.append(None)
             elif op == "ds_write_addtid_b32":
                 off = int(re.search(r"offset:(\d+)", rest).group(1)) if "offset:" in rest else 0
                 assert (self.m0 < 65536).all(), "the M0-relative store takes its base from M0[15:0]"

@@ -27,7 +27,7 @@ WAVES = int(os.environ.get("PBS_ASM_WAVES", "8"))     # bootstraps per workgroup
 assert WAVES in (4, 8)
 ROWS_PER_WAVE = 16 // WAVES                          # LDS-DMA rows of a key chunk each wave fetches
 # schedule choices that can be switched off for measurement (PBS_ASM_OPT=comma list replaces the default set)
-OPT = set(f for f in os.environ.get("PBS_ASM_OPT", "mac_il,tw_spread,inv_split,lanesum,ls_pf2").split(",") if f)
+OPT = set(f for f in os.environ.get("PBS_ASM_OPT", "mac_il,tw_spread,inv_split,lanesum,ls_pf2,wait_merge").split(",") if f)
 # "lanesum": the sum over the four polynomials stays inside a lane.  After the second forward pass the four lanes of a quad
 # exchange frequency groups (in-place DPP moves) so that lane x holds, for ALL four polynomials and both levels, the four bins
 # whose high index digit is x; the products then accumulate in registers (no reduce-scatter of partial sums: 48 DPP moves and
@@ -453,9 +453,16 @@ class Loop:
     def exchange_plane(self, X, plane):
         """16 x 16 exchange of one real plane: element r of this lane -> [r][t], row t back into the home slots in
         natural order.  Only issues; the caller waits."""
-        for r in range(16):
-            reg = X.slot(X.pos[r])[plane]
-            self.e("ds_write_b64 v%d, %s offset:%d" % (V_TRWR[r >> 2], dreg(reg), r * 128))
+        if "write2" in OPT:     # two elements of a four-group per store: half the store instructions, and 1.4 % SLOWER in the
+            # kernel (223.4 k against 226.5 k bootstraps/s in one GPU call): the paired store occupies the LDS path longer
+            # than the two single ones; kept for the record, not in the default set
+            for r in range(0, 16, 2):
+                r0, r1 = X.slot(X.pos[r])[plane], X.slot(X.pos[r + 1])[plane]
+                self.e("ds_write2_b64 v%d, %s, %s offset0:%d offset1:%d" % (V_TRWR[r >> 2], dreg(r0), dreg(r1), r * 16, (r + 1) * 16))
+        else:
+            for r in range(16):
+                reg = X.slot(X.pos[r])[plane]
+                self.e("ds_write_b64 v%d, %s offset:%d" % (V_TRWR[r >> 2], dreg(reg), r * 128))
         base = X.base + 32 * plane
         for w in range(8):
             self.e("ds_read_b128 %s, v%d offset:%d" % (qreg(base + 4 * w), V_TRRD[w & 3], 64 * (w >> 2)))
@@ -662,7 +669,12 @@ class Loop:
                 for reg in regs_of(ln.split(None, 1)[1].split(",")[0]):
                     last[reg] = i
         stores = []
-        for r in range(16):
+        if "write2" in OPT:
+            for r in range(0, 16, 2):
+                r0, r1 = X.slot(X.pos[r])[0], X.slot(X.pos[r + 1])[0]
+                at = max(last.get(("v", r0), -1), last.get(("v", r1), -1))
+                stores.append((at, "ds_write2_b64 v%d, %s, %s offset0:%d offset1:%d" % (V_TRWR[r >> 2], dreg(r0), dreg(r1), r * 16, (r + 1) * 16)))
+        for r in range(0 if "write2" not in OPT else 16, 16):
             reg = X.slot(X.pos[r])[0]
             stores.append((last.get(("v", reg), -1), "ds_write_b64 v%d, %s offset:%d" % (V_TRWR[r >> 2], dreg(reg), r * 128)))
         for at, ln in sorted(stores, key=lambda x: -x[0]):
@@ -804,21 +816,36 @@ def place_waits(lines):
     barrier of the key ring waits for every key read issued before it (the chunk they came from is refilled after
     the barrier).  A DPP move needs two wait states after the vector instruction that wrote its source."""
     body = [ln for ln in lines if not (ln.startswith("s_waitcnt lgkmcnt(") or ln == "s_nop 1")]
-    out, queue, recent = [], [], []          # queue: [dst regs, is key read] of LDS operations in flight, oldest first
-    for ln in body:
+    # "wait_merge": an s_waitcnt is an instruction like any other and takes an issue slot.  When reads that were issued long
+    # ago (at least MERGE_AGE instructions back) are first used within the next MERGE_AHEAD instructions, one wait covers them
+    # all: it waits for the youngest of them, which the in-order return makes a wait for every older one too.
+    merge = "wait_merge" in OPT
+    MERGE_AHEAD, MERGE_AGE = 16, 24
+    touched_at = [regs_of(ln.split(None, 1)[1]) if (" " in ln and not ln.endswith(":")) else set() for ln in body]
+    out, queue, recent = [], [], []          # queue: [dst regs, is key read, issue index] of LDS operations in flight, oldest first
+    for pos, ln in enumerate(body):
         if ln.endswith(":"):
             assert not any(q[0] for q in queue), "LDS reads in flight across a label"
             out.append(ln)
             continue
         op = ln.split()[0]
-        touched = regs_of(ln.split(None, 1)[1]) if " " in ln else set()
+        touched = touched_at[pos]
         need = -1
-        for k, (dst, is_key) in enumerate(queue):
+        for k, (dst, is_key, _) in enumerate(queue):
             if (dst & touched) or (is_key and op == "s_barrier"):
                 need = k
         if op == "s_cbranch_scc1" or "vmcnt(0) lgkmcnt(0)" in ln:
             need = max([k for k, q in enumerate(queue) if q[0]], default=-1)
         if need >= 0:
+            if merge:
+                soon = set()
+                for nxt in range(pos + 1, min(pos + 1 + MERGE_AHEAD, len(body))):
+                    if body[nxt].endswith(":") or body[nxt].split()[0] in ("s_barrier", "s_cbranch_scc1"):
+                        break
+                    soon |= touched_at[nxt]
+                for k in range(need + 1, len(queue)):
+                    if queue[k][0] and (queue[k][0] & soon) and queue[k][2] <= pos - MERGE_AGE:
+                        need = k
             n = min(len(queue) - 1 - need, 15)
             out.append("s_waitcnt lgkmcnt(%d)" % n)
             queue = queue[len(queue) - n:] if n else []
@@ -833,7 +860,7 @@ def place_waits(lines):
                     break
         out.append(ln)
         if op.startswith("ds_"):
-            queue.append((lds_dst(ln), op == "ds_read_b128" and ", v%d " % V_KADDR in ln + " "))
+            queue.append((lds_dst(ln), op == "ds_read_b128" and ", v%d " % V_KADDR in ln + " ", pos))
         if op.startswith("v_"):
             recent.append(regs_of(ln.split(None, 1)[1].split(",")[0]))
         elif not op.startswith("s_waitcnt"):
