@@ -278,12 +278,13 @@ class Machine:
                 self.vm_queue.append((r0, [words[..., k].copy() for k in range(4)]))
             elif op == "global_load_lds_dwordx4":
                 voff = self.src32(a[0]).astype(np.int64)
-                m = re.fullmatch(r"s\[(\d+):(\d+)\]", a[1])
+                m = re.match(r"s\[(\d+):(\d+)\]", a[1])
                 r = int(m.group(1))
                 base = self.s[r].astype(np.int64) | (self.s[r + 1].astype(np.int64) << 32)
-                src = base[:, None] + voff
+                off = int(re.search(r"offset:(\d+)", rest).group(1)) if "offset:" in rest else 0   # moves both addresses
+                src = base[:, None] + voff + off
                 data = self.key[src[..., None] + np.arange(16)]
-                dst = self.m0.astype(np.int64)[:, None] + np.arange(L) * 16
+                dst = self.m0.astype(np.int64)[:, None] + off + np.arange(L) * 16
                 self.dma_queue.append((dst[..., None] + np.arange(16), data))
             else:
                 raise NotImplementedError(ln)

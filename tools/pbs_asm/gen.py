@@ -27,7 +27,7 @@ WAVES = int(os.environ.get("PBS_ASM_WAVES", "8"))     # bootstraps per workgroup
 assert WAVES in (4, 8)
 ROWS_PER_WAVE = 16 // WAVES                          # LDS-DMA rows of a key chunk each wave fetches
 # schedule choices that can be switched off for measurement (PBS_ASM_OPT=comma list replaces the default set)
-OPT = set(f for f in os.environ.get("PBS_ASM_OPT", "mac_il,tw_spread,inv_split,lanesum,ls_pf2,wait_merge").split(",") if f)
+OPT = set(f for f in os.environ.get("PBS_ASM_OPT", "mac_il,tw_spread,inv_split,lanesum,ls_pf2,wait_merge,dma_off").split(",") if f)
 # "lanesum": the sum over the four polynomials stays inside a lane.  After the second forward pass the four lanes of a quad
 # exchange frequency groups (in-place DPP moves) so that lane x holds, for ALL four polynomials and both levels, the four bins
 # whose high index digit is x; the products then accumulate in registers (no reduce-scatter of partial sums: 48 DPP moves and
@@ -485,6 +485,19 @@ class Loop:
         else:
             off = qq * 8192 if qq < 8 else STEP_KEY_BYTES + (qq - 8) * 8192
         slot = qq % 4
+        if "dma_off" in OPT:
+            # one row pointer and one M0 per chunk: the instruction's offset moves the global address AND the LDS address of
+            # an LDS-DMA load, so the wave's further rows (contiguous in the key, 1 KiB apart in the ring) need no scalar work;
+            # the ring slot of the key reads sits in their offset field, so the read address register never changes
+            assert LANESUM, "rows of a wave are contiguous only in the lane-local-sum key layout"
+            e("s_add_u32 s%d, s%d, 0x%x" % (S_TMP, S_KP, off))
+            e("s_addc_u32 s%d, s%d, 0" % (S_TMP + 1, S_KP + 1))
+            e("s_add_u32 m0, s%d, 0x%x" % (S_M0ROW, slot * K_CHUNK_BYTES))
+            e("s_nop 0")
+            for j in range(ROWS_PER_WAVE):
+                e("global_load_lds_dwordx4 v%d, s[%d:%d]%s" % (V_LANE16, S_TMP, S_TMP + 1, " offset:%d" % (1024 * j) if j else ""))
+            self.ring_slot = q % 4
+            return
         for j in range(ROWS_PER_WAVE):
             if j == 0:
                 e("s_add_u32 s%d, s%d, 0x%x" % (S_TMP, S_KP, off))
@@ -588,8 +601,9 @@ class Loop:
 
     def key_issue_ls(self, lv, j, buf):
         """key words [j][j' = 0..3] of the chunk (k_lo, lv) at hand, into key buffer `buf`"""
+        base = self.ring_slot * K_CHUNK_BYTES if "dma_off" in OPT else 0
         for jp in range(4):
-            self.e("ds_read_b128 %s, v%d offset:%d" % (qreg(buf + 4 * jp), V_KADDR, (4 * j + jp) * 1024))
+            self.e("ds_read_b128 %s, v%d offset:%d" % (qreg(buf + 4 * jp), V_KADDR, base + (4 * j + jp) * 1024))
 
     def mac_lanesum(self, A, B):
         """A[position (k_lo, j')] <- sum over levels and slot sets j of spectrum[lv][(k_lo, j)] x key[k_lo][lv][j][j'].  Eight
@@ -776,6 +790,8 @@ class Loop:
         mbits = struct.unpack("<Q", struct.pack("<d", MAGIC))[0]
         e("v_mov_b32 v%d, 0x%x" % (V_MAGIC, mbits & 0xFFFFFFFF))
         e("v_mov_b32 v%d, 0x%x" % (V_MAGIC + 1, mbits >> 32))
+        if "dma_off" in OPT:
+            e("v_add_u32 v%d, 0x%x, v%d" % (V_KADDR, K_RING_OFFSET, V_KBASE))
         e("L_step%=:")
         self.out.extend(place_waits(body.out) if AUTO_WAITS else body.out)
         e("s_add_u32 s%d, s%d, 0x%x" % (S_KP, S_KP, STEP_KEY_BYTES))
