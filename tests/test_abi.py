@@ -66,3 +66,12 @@ def test_no_cpu_fallback_without_a_gpu():
     from tfhe_aes_amd import host as H
     with pytest.raises(H.HostError):
         H.gen_keys(1, 0)
+
+
+def test_profile_launches_refuses_null_arguments():
+    """no context is needed to see the argument checks of the entry point added for the bench's per-width table"""
+    import ctypes as C
+    from tfhe_aes_amd import engine as E
+    lib = E.load_library()
+    n = C.c_uint32(0)
+    assert lib.tfa_profile_launches(None, None, C.c_uint32(0), C.byref(n)) == -1      # TFA_EINVAL

@@ -412,3 +412,37 @@ def test_zero_decryption_failures_over_a_million_gates(gpu_ctx, oracle, okeys):
         x, y = exp, x  # next round: a = this output, b = previous a
         src_a, src_b, dst = dst, src_a, src_b
     assert failures == 0
+
+
+@pytest.mark.gpu
+def test_profile_launches_records_every_timed_launch(gpu_ctx, oracle, okeys):
+    """tfa_profile_launches: one record per bootstrap / keyswitch launch of the stages submitted while profiling is on, in
+    order, with the stage's unit counts (a MUX is two bootstraps and one keyswitch) and the mapping that ran it; cleared by
+    tfa_reset_stats; nothing is recorded while profiling is off."""
+    from tfhe_aes_amd import engine as E
+    ctx, p = gpu_ctx, E.default_params()
+    lwe_sk = okeys[0]
+    widths = [100, 300, 1000, 2500]
+    G = max(widths)
+    ctx.pool_reserve(4 * G)
+    bits = np.random.default_rng(5).integers(0, 2, 3 * G).astype(np.uint8)
+    ctx.pool_write(np.arange(3 * G), oracle.encrypt_bits(lwe_sk, 41, 0, bits))
+    ctx.reset_stats()
+    ctx.set_profiling(True)
+    for w in widths:
+        ops = np.where(np.arange(w) % 2 == 0, E.MUX, E.XOR)
+        ctx.stage_submit(E.make_gates(ops, np.arange(w), np.arange(G, G + w), np.arange(2 * G, 2 * G + w), np.arange(3 * G, 3 * G + w)))
+    rec = ctx.profile_launches()
+    ctx.set_profiling(False)
+    pbs, ks = rec[rec["kind"] == 0], rec[rec["kind"] == 1]
+    assert list(ks["units"]) == widths
+    assert list(pbs["units"]) == [w + (w + 1) // 2 for w in widths]
+    assert (rec["ms"] > 0).all()
+    # mapping: 1 / 2 = one bootstrap per workgroup (narrow stages), 4 / 8 = one per wave, 8 | tail << 8 = full rounds plus a tail
+    assert all((m & 0xFF) in (1, 2, 4, 8) for m in pbs["mapping"]) and (pbs["mapping"][0] & 0xFF) in (1, 2)
+    st = ctx.stats()
+    assert st.pbs_launches == len(widths) and abs(st.pbs_kernel_ms - float(pbs["ms"].sum())) < 1e-3 * st.pbs_kernel_ms + 1e-3
+    ctx.stage_submit(E.make_gates([E.XOR], [0], [1], None, [3 * G]))      # profiling off: no new record
+    assert len(ctx.profile_launches()) == len(rec)
+    ctx.reset_stats()
+    assert len(ctx.profile_launches()) == 0
