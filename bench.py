@@ -199,6 +199,16 @@ def aes_single_gpu(device, chains=True):
         ecb.decrypt(state)
     out.update(leg.fields("ecb_decrypt_block"))
     out["ecb_decrypt_correct"] = state.decrypt_to_u8().hex() == fb["plaintext"]
+    # the same block with every gate in the association the reference's code records it in (no re-association of xor chains:
+    # MixColumns and AddRoundKey as five dependent xor layers instead of three): same gates, 117 stages
+    keys.set_xor_rebalance(False)
+    state = H.State.from_u8_enc(bytes.fromhex(fb["plaintext"]), keys)
+    with Leg(keys) as leg:
+        ecb.encrypt(state)
+    out.update(leg.fields("ecb_encrypt_block_as_recorded"))
+    out["ecb_encrypt_block_as_recorded_correct"] = state.decrypt_to_u8().hex() == fb["ciphertext"]
+    keys.set_xor_rebalance(True)
+    out["xor_chain_rebalance"] = "on (default) for every leg but *_as_recorded: same gates and results, fewer dependent stages"
     # the same encryption once more with HIP events around every launch (outside the timed leg above): where the block's time goes
     state = H.State.from_u8_enc(bytes.fromhex(fb["plaintext"]), keys)
     keys.flush()

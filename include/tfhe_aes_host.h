@@ -33,6 +33,11 @@ void tfh_keys_free(tfh_keys *k);
 tfa_ctx *tfh_context(tfh_keys *k);
 int tfh_flush(tfh_keys *k);
 int tfh_host_stats(tfh_keys *k, uint64_t out[4]); /* gates, stages, flushes, widest stage */
+/* Scheduling switch of the lazy ServerKey that stands in for the rayon pool of primitive.rs:250-265 (no counterpart in the
+ * reference): on (default), chains of xor gates whose intermediate values have no live handle are re-associated into trees of
+ * least depth before they run - same gates, same decrypted results, fewer dependent stages (one ECB block: 99 instead of 117).
+ * Off: every gate runs in the association the caller recorded. */
+int tfh_set_xor_rebalance(tfh_keys *k, int on);
 int tfh_lwe_secret_key(tfh_keys *k, uint32_t *out /*[n]*/);
 
 /* Ciphertext-level gate API: ClientKey::{encrypt,decrypt}, ServerKey::{trivial_encrypt,and,...,mux,not} */

@@ -83,6 +83,94 @@ pub struct HostStats {
     pub max_stage_width: u64,
 }
 
+/// Re-associates chains of xor / xnor gates whose intermediate results nobody can observe: an intermediate whose last
+/// handle is gone (its slot is in `dead`) and that is read by exactly one recorded gate, itself an xor / xnor.  Such a chain
+/// is one n-input parity: it is rebuilt with the same n - 1 xor gates, on the same slots, as the tree of least depth for the
+/// levels at which its operands become available (the two earliest are combined first), and every gate of the recording is
+/// levelled again.  MixColumns followed by AddRoundKey (state.rs:72-118, 217-224), five dependent xor layers per output
+/// bit, becomes three levels: one ECB block takes 99 stages instead of 117.  Operand negations and xnors are gathered into
+/// one negation at the root.  Gate counts, gate kinds and decrypted results do not change.
+fn rebalance_xor_chains(levels: Vec<Vec<sys::tfa_gate>>, dead: &[u32], n_slots: usize) -> Vec<Vec<sys::tfa_gate>> {
+    use std::cmp::Reverse;
+    use std::collections::BinaryHeap;
+    let gates: Vec<sys::tfa_gate> = levels.iter().flatten().copied().collect(); // level order is a topological order
+    let n = gates.len();
+    let operands = |g: &sys::tfa_gate| -> Vec<u32> {
+        if g.op == sys::TFA_MUX { vec![g.in0, g.in1, g.in2] } else { vec![g.in0, g.in1] }
+    };
+    let is_xor = |g: &sys::tfa_gate| g.op == sys::TFA_XOR || g.op == sys::TFA_XNOR;
+    let mut producer = vec![usize::MAX; n_slots];
+    for (i, g) in gates.iter().enumerate() {
+        producer[g.out as usize] = i;
+    }
+    let mut is_dead = vec![false; n_slots];
+    for &s in dead {
+        is_dead[s as usize] = true;
+    }
+    let (mut uses, mut user) = (vec![0u32; n], vec![usize::MAX; n]);
+    for (i, g) in gates.iter().enumerate() {
+        for s in operands(g) {
+            let p = producer[s as usize];
+            if p != usize::MAX {
+                uses[p] += 1;
+                user[p] = i;
+            }
+        }
+    }
+    let absorbed: Vec<bool> =
+        (0..n).map(|i| is_xor(&gates[i]) && is_dead[gates[i].out as usize] && uses[i] == 1 && is_xor(&gates[user[i]])).collect();
+    if !absorbed.iter().any(|&a| a) {
+        return levels;
+    }
+    let mut level = vec![0u32; n_slots];
+    let mut out: Vec<Vec<sys::tfa_gate>> = Vec::new();
+    fn put(out: &mut Vec<Vec<sys::tfa_gate>>, level: &mut [u32], g: sys::tfa_gate, lvl: u32) {
+        while out.len() < lvl as usize {
+            out.push(Vec::new());
+        }
+        out[lvl as usize - 1].push(g);
+        level[g.out as usize] = lvl;
+    }
+    for i in 0..n {
+        if absorbed[i] {
+            continue;
+        }
+        let g = gates[i];
+        let is_root = is_xor(&g) && [g.in0, g.in1].iter().any(|&s| producer[s as usize] != usize::MAX && absorbed[producer[s as usize]]);
+        if !is_root {
+            let lvl = operands(&g).iter().map(|&s| level[s as usize]).max().unwrap_or(0);
+            put(&mut out, &mut level, g, lvl + 1);
+            continue;
+        }
+        let mut heap: BinaryHeap<Reverse<(u32, u32, u32)>> = BinaryHeap::new(); // (level, arrival, slot): earliest first
+        let (mut spare, mut stack, mut parity, mut seq) = (Vec::new(), vec![i], 0u32, 0u32);
+        while let Some(j) = stack.pop() {
+            let x = gates[j];
+            parity ^= (x.op == sys::TFA_XNOR) as u32 ^ (x.neg & 1) ^ ((x.neg >> 1) & 1);
+            for s in [x.in0, x.in1] {
+                let p = producer[s as usize];
+                if p != usize::MAX && absorbed[p] {
+                    spare.push(s);
+                    stack.push(p);
+                } else {
+                    heap.push(Reverse((level[s as usize], seq, s)));
+                    seq += 1;
+                }
+            }
+        }
+        while heap.len() > 2 {
+            let (Reverse(a), Reverse(b)) = (heap.pop().unwrap(), heap.pop().unwrap());
+            let (slot, lvl) = (spare.pop().unwrap(), a.0.max(b.0) + 1);
+            put(&mut out, &mut level, sys::tfa_gate { op: sys::TFA_XOR, in0: a.2, in1: b.2, in2: 0, out: slot, neg: 0 }, lvl);
+            heap.push(Reverse((lvl, seq, slot)));
+            seq += 1;
+        }
+        let (Reverse(a), Reverse(b)) = (heap.pop().unwrap(), heap.pop().unwrap());
+        put(&mut out, &mut level, sys::tfa_gate { op: sys::TFA_XOR, in0: a.2, in1: b.2, in2: 0, out: g.out, neg: parity }, a.0.max(b.0) + 1);
+    }
+    out
+}
+
 struct Engine {
     ctx: *mut sys::tfa_ctx,
     next_fresh: u32,
@@ -90,6 +178,7 @@ struct Engine {
     free: Vec<u32>,                  // slots whose readers have all been submitted
     released: Arc<Mutex<Vec<u32>>>,  // slots dropped since the last flush: recorded gates may still read them
     recording: bool,
+    xor_rebalance: bool,             // re-associate unobservable xor chains before a flush (rebalance_xor_chains)
     levels: Vec<Vec<sys::tfa_gate>>, // levels[l - 1] = the recorded gates of dependency level l
     pending_gates: usize,
     stats: HostStats,
@@ -122,7 +211,13 @@ impl Engine {
     }
     /// Runs the recording: one stage per level, then the slots released meanwhile become reusable.
     fn flush(&mut self, epoch: &AtomicU64) {
-        for lv in self.levels.drain(..).collect::<Vec<_>>() {
+        let mut levels = std::mem::take(&mut self.levels);
+        if self.xor_rebalance && self.pending_gates > 0 {
+            // a slot on the list has no handle left and cannot get one again; one dropped after this snapshot counts as live
+            let dead = self.released.lock().unwrap().clone();
+            levels = rebalance_xor_chains(levels, &dead, self.next_fresh as usize);
+        }
+        for lv in levels {
             if lv.is_empty() {
                 continue;
             }
@@ -183,7 +278,7 @@ pub fn gen_keys_on(hip_device: i32, seed: u64) -> (ClientKey, ServerKey) {
         assert_eq!(rc, sys::TFA_OK, "tfa_ctx_create failed: is a gfx950 GPU visible?");
         let released = Arc::new(Mutex::new(Vec::new()));
         let engine = Engine {
-            ctx, next_fresh: 0, capacity: 0, free: Vec::new(), released: released.clone(), recording: true, levels: Vec::new(), pending_gates: 0,
+            ctx, next_fresh: 0, capacity: 0, free: Vec::new(), released: released.clone(), recording: true, xor_rebalance: true, levels: Vec::new(), pending_gates: 0,
             stats: HostStats::default(),
         };
         engine.check(sys::tfa_keys_upload(ctx, bsk.as_ptr(), ksk.as_ptr()));
@@ -280,6 +375,11 @@ impl ServerKey {
         e.recording = on;
     }
     /// Runs the recorded gates, one `tfa_stage_submit` per dependency level, and waits for them.
+    /// On (the default): chains of xor gates whose intermediate values have no live handle are re-associated into trees of
+    /// least depth before a flush (`rebalance_xor_chains`); off: every gate runs in the association it was recorded in.
+    pub fn set_xor_rebalance(&self, on: bool) {
+        self.engine.lock().unwrap().xor_rebalance = on;
+    }
     pub fn flush(&self) {
         self.engine.lock().unwrap().flush(&self.epoch);
     }

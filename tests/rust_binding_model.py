@@ -7,10 +7,74 @@ tfa_stage_submit.  tests/test_rust_source_matches_model.py compares the gate cal
 
 A ciphertext is ("E", SlotRef, negated) or ("T", bool).  A ServerKey owns slot allocation, levels and flushing; its
 backend executes: submit(list of gate dicts), write(slots, bits), read(slots) -> bits."""
+import heapq
+
 from oracle import boolean_tree_oracle as B
 
 AND, NAND, OR, NOR, XOR, XNOR, MUX, NOT, COPY = range(9)
 AUTO_FLUSH_GATES = 2_000_000
+
+
+def rebalance_xor_chains(levels, dead):         # hip.rs rebalance_xor_chains
+    """Chains of xor / xnor gates whose intermediate results are unobservable (slot in `dead`: no handle left; read by exactly
+    one recorded gate, itself an xor / xnor) are rebuilt, with the same number of xor gates on the same slots, as the tree of
+    least depth for the levels at which their operands become available; every gate is levelled again.  Operand negations
+    and xnors are gathered into one negation at the root."""
+    gates = [g for lv in levels for g in lv]    # level order is a topological order
+    producer = {g["out"]: i for i, g in enumerate(gates)}
+    uses, user = [0] * len(gates), [-1] * len(gates)
+
+    def operands(g):
+        return [g["in0"], g["in1"]] + ([g["in2"]] if g["op"] == MUX else [])
+
+    def is_xor(g):
+        return g["op"] in (XOR, XNOR)
+
+    for i, g in enumerate(gates):
+        for s in operands(g):
+            p = producer.get(s, -1)
+            if p >= 0:
+                uses[p] += 1
+                user[p] = i
+    absorbed = [is_xor(g) and g["out"] in dead and uses[i] == 1 and is_xor(gates[user[i]]) for i, g in enumerate(gates)]
+    if not any(absorbed):
+        return levels
+    level, out = {}, []
+
+    def put(g, lvl):
+        while len(out) < lvl:
+            out.append([])
+        out[lvl - 1].append(g)
+        level[g["out"]] = lvl
+
+    for i, g in enumerate(gates):
+        if absorbed[i]:
+            continue
+        if not (is_xor(g) and any(producer.get(s, -1) >= 0 and absorbed[producer[s]] for s in operands(g))):
+            put(g, 1 + max(level.get(s, 0) for s in operands(g)))
+            continue
+        heap, spare, parity, stack = [], [], 0, [i]
+        while stack:
+            x = gates[stack.pop()]
+            parity ^= int(x["op"] == XNOR) ^ (x["neg"] & 1) ^ ((x["neg"] >> 1) & 1)
+            for s in (x["in0"], x["in1"]):
+                p = producer.get(s, -1)
+                if p >= 0 and absorbed[p]:
+                    spare.append(s)
+                    stack.append(p)
+                else:
+                    heap.append((level.get(s, 0), len(heap), s))
+        seq = len(heap)
+        heapq.heapify(heap)
+        while len(heap) > 2:
+            a, b = heapq.heappop(heap), heapq.heappop(heap)
+            slot, lvl = spare.pop(), max(a[0], b[0]) + 1
+            put(dict(op=XOR, in0=a[2], in1=b[2], in2=0, out=slot, neg=0), lvl)
+            heapq.heappush(heap, (lvl, seq, slot))
+            seq += 1
+        a, b = heapq.heappop(heap), heapq.heappop(heap)
+        put(dict(op=XOR, in0=a[2], in1=b[2], in2=0, out=g["out"], neg=parity), max(a[0], b[0]) + 1)
+    return out
 
 
 def trivial(b):
@@ -40,6 +104,7 @@ class ServerKey:                                # hip.rs ServerKey + Engine
         self.backend = backend
         self.next_fresh, self.free, self.released = 0, [], []
         self.recording, self.levels, self.pending_gates, self.epoch = recording, [], 0, 0
+        self.xor_rebalance = True
         self.stats = dict(gates=0, stages=0, flushes=0, max_stage_width=0)
 
     def alloc(self):                            # Engine::alloc
@@ -59,6 +124,8 @@ class ServerKey:                                # hip.rs ServerKey + Engine
 
     def flush(self):                            # Engine::flush
         levels, self.levels = self.levels, []
+        if self.xor_rebalance and self.pending_gates:
+            levels = rebalance_xor_chains(levels, set(self.released))
         for lv in levels:
             if lv:
                 self._submitted(lv)
@@ -67,6 +134,9 @@ class ServerKey:                                # hip.rs ServerKey + Engine
         self.epoch += 1
         self.free.extend(self.released)
         del self.released[:]
+
+    def set_xor_rebalance(self, on):
+        self.xor_rebalance = on
 
     def set_recording(self, on):
         self.flush()

@@ -121,8 +121,12 @@ def test_key_schedule_online(hkeys):  # key_schedule.rs:220-246 prints; here the
     assert [rk.decrypt_to_u8() for rk in clear] == expected
 
 
-ECB_ENCRYPT_STAGES = 117
-ECB_DECRYPT_STAGES = 144
+# Dependent stages of one block.  As recorded (set_xor_rebalance(False)): 117 / 144.  With the default re-association of
+# unobservable xor chains (MixColumns + AddRoundKey: three levels instead of five): 99 / 135.
+ECB_ENCRYPT_STAGES_AS_RECORDED = 117
+ECB_DECRYPT_STAGES_AS_RECORDED = 144
+ECB_ENCRYPT_STAGES = 99
+ECB_DECRYPT_STAGES = 135
 
 
 def offline_round_keys(key, hkeys):
@@ -134,21 +138,28 @@ def test_ecb_once(hkeys):  # modes/src/ecb.rs:62-89, FIPS-197 Appendix B
     v = V["fips197_b"]
     ecb = H.ECB(offline_round_keys(h(v["key"]), hkeys))
     state = H.State.from_u128_enc(int(v["plaintext"], 16), hkeys)
-    before = hkeys.host_stats()
-    ecb.encrypt(state)
-    assert state.decrypt_to_u128() == int(v["ciphertext"], 16)
-    after = hkeys.host_stats()
-    assert after["gates"] - before["gates"] == 71824
     # the batch submitter levels the recorded gates by data dependence: 117 stages where the reference's loop
-    # order has 126 (ecb.rs:16-32); the inverse cipher levels to ECB_DECRYPT_STAGES where it has 198 (ecb.rs:34-50,
-    # state.rs:120-215)
-    assert after["stages"] - before["stages"] == ECB_ENCRYPT_STAGES
-    before = after
-    ecb.decrypt(state)
-    assert state.decrypt_to_u128() == int(v["plaintext"], 16)
-    after = hkeys.host_stats()
-    assert after["gates"] - before["gates"] == 75604
-    assert after["stages"] - before["stages"] == ECB_DECRYPT_STAGES
+    # order has 126 (ecb.rs:16-32); the inverse cipher levels to 144 where it has 198 (ecb.rs:34-50, state.rs:120-215);
+    # re-associating the xor chains (the default) takes the same gates in 99 / 135 stages
+    try:
+        for rebalance, enc_stages, dec_stages in ((False, ECB_ENCRYPT_STAGES_AS_RECORDED, ECB_DECRYPT_STAGES_AS_RECORDED),
+                                                  (True, ECB_ENCRYPT_STAGES, ECB_DECRYPT_STAGES)):
+            hkeys.set_xor_rebalance(rebalance)
+            state = H.State.from_u128_enc(int(v["plaintext"], 16), hkeys)
+            before = hkeys.host_stats()
+            ecb.encrypt(state)
+            assert state.decrypt_to_u128() == int(v["ciphertext"], 16)
+            after = hkeys.host_stats()
+            assert after["gates"] - before["gates"] == 71824
+            assert after["stages"] - before["stages"] == enc_stages
+            before = after
+            ecb.decrypt(state)
+            assert state.decrypt_to_u128() == int(v["plaintext"], 16)
+            after = hkeys.host_stats()
+            assert after["gates"] - before["gates"] == 75604
+            assert after["stages"] - before["stages"] == dec_stages
+    finally:
+        hkeys.set_xor_rebalance(True)
 
 
 @pytest.mark.timeout(300)
@@ -242,7 +253,8 @@ def test_config5_64_ctr_blocks_sharded_over_8_ranks(hkeys):
         H.CTR(rk, counters, len(mine)).encrypt(states)
         local = torch.empty((len(mine), 128, words), dtype=torch.int32, device="cuda:0")
         H.read_states_device(states, local)
-        assert hkeys.host_stats()["stages"] - before == ECB_ENCRYPT_STAGES + 1   # 8 blocks share the stages; + the final xor
+        # 8 blocks share the stages; the final xor with the plaintext joins the last AddRoundKey's xor tree: no stage of its own
+        assert hkeys.host_stats()["stages"] - before == ECB_ENCRYPT_STAGES
         shards.append(local)
     # what all_gather_into_tensor + the reorder of shard.gather_blocks_device produce: rank-major shards -> block order
     allbuf = torch.cat(shards)
@@ -252,3 +264,73 @@ def test_config5_64_ctr_blocks_sharded_over_8_ranks(hkeys):
     exp = [bytes(x ^ y for x, y in zip(B.aes_encrypt_block(B.key_expansion_clear(key), ((c0 + i) % (1 << 128)).to_bytes(16, "big")), pts[i])) for i in range(n_blocks)]
     assert got == exp
     assert [x.hex() for x in got[:4]] == v["ctr"]
+
+
+@pytest.mark.timeout(300)
+def test_xor_chain_rebalance_random_circuits(hkeys):
+    """ServerKey's re-association of unobservable xor chains (tfhe_boolean.cpp: rebalance_xor_chains) on random circuits: xor /
+    xnor chains with negated operands, intermediates that are dropped (re-associated), kept (observable: must keep their
+    value) or shared by two consumers, other gates and muxes in between.  Every kept handle decrypts to the clear evaluation,
+    the gate count is the recorded one, and the stages are never more than without the re-association."""
+    k = hkeys
+    rng = np.random.default_rng(20240607)
+    stages = {}
+    try:
+        for rebalance in (False, True):
+            k.set_xor_rebalance(rebalance)
+            rng = np.random.default_rng(77)
+            before = k.host_stats()
+            checked = 0
+            for trial in range(6):
+                vals = [bool(b) for b in rng.integers(0, 2, 12)]
+                live = [(k.encrypt(v), v) for v in vals]                     # (handle, clear value)
+                kept = []
+                for step in range(120):
+                    kind = rng.integers(0, 10)
+                    pick = lambda: live[rng.integers(max(0, len(live) - 6), len(live))] if rng.integers(0, 3) else live[rng.integers(0, len(live))]
+                    a, b = pick(), pick()
+                    if rng.integers(0, 4) == 0:
+                        a = (k.not_(a[0]), not a[1])
+                    if kind < 6:
+                        r = (k.xor(a[0], b[0]), a[1] != b[1]) if rng.integers(0, 4) else (k.xnor(a[0], b[0]), a[1] == b[1])
+                    elif kind < 8:
+                        r = (k.and_(a[0], b[0]), a[1] and b[1])
+                    else:
+                        c = pick()
+                        r = (k.mux(c[0], a[0], b[0]), a[1] if c[1] else b[1])
+                    if rng.integers(0, 5) == 0:
+                        kept.append(r)                                       # observable for good
+                    live.append(r)
+                    if len(live) > 14 and rng.integers(0, 2):                # drop an older handle: what it fed may re-associate
+                        del live[rng.integers(12, len(live) - 1)]
+                kept.extend(live[12:])
+                del live
+                for ct, want in kept:
+                    assert k.decrypt(ct) == want
+                    checked += 1
+            after = k.host_stats()
+            stages[rebalance] = (after["stages"] - before["stages"], after["gates"] - before["gates"])
+            assert checked > 100
+    finally:
+        k.set_xor_rebalance(True)
+    assert stages[True][1] == stages[False][1]           # same gates
+    assert stages[True][0] <= stages[False][0]           # never more dependent stages
+    # a plain chain of eight operands, intermediates dropped, one operand negated, one link an xnor: 7 gates in 3 stages
+    # instead of 7; with the middle of the chain kept by the caller the two halves re-associate on their own (2 + 2 stages)
+    bits = [True, False, True, True, False, False, True, False]
+    for keep_middle, want_stages in ((False, 3), (True, 4)):
+        cts = [k.encrypt(b) for b in bits]
+        k.flush()
+        before = k.host_stats()
+        acc, clear, middle = cts[0], bits[0], None
+        for i in range(1, 8):
+            rhs = k.not_(cts[i]) if i == 2 else cts[i]
+            acc = k.xnor(acc, rhs) if i == 5 else k.xor(acc, rhs)
+            clear = (clear != (bits[i] != (i == 2))) != (i == 5)
+            if i == 4 and keep_middle:
+                middle = (acc, clear)
+        assert k.decrypt(acc) == clear
+        if middle:
+            assert k.decrypt(middle[0]) == middle[1]
+        after = k.host_stats()
+        assert after["gates"] - before["gates"] == 7 and after["stages"] - before["stages"] == want_stages

@@ -100,19 +100,25 @@ def test_trivial_operands_never_reach_the_engine():
 def test_recording_key_levels_one_block_like_the_host_mirror():
     """A recording key files every gate at 1 + its deepest operand's level: one ECB block (ecb.rs:16-32, unchanged caller)
     takes the 117 stages and 71 824 gates of the C++ mirror's lazy submitter, against 126 submits on an eager key, and
-    decrypts to the FIPS-197 Appendix B ciphertext; the inverse cipher (ecb.rs:34-50) takes 144 stages and returns the block."""
-    eng = M.ClearEngine()
-    sk = M.ServerKey(eng)
-    keys = [M.Key.from_u8_enc(k, sk) for k in B.key_expansion_clear(FIPS_KEY)]
-    st = M.State.from_u8_enc(FIPS_PT, sk)
-    M.ecb_encrypt(st, keys, sk)
-    assert eng.stages == []                                   # nothing runs before the first decrypt
-    assert st.decrypt_to_u8(sk).hex() == FIPS_CT
-    assert (sk.stats["stages"], sk.stats["gates"]) == (117, 71824)
-    assert sum(2 if g["op"] == M.MUX else 1 for s in eng.stages for g in s) == 127872
-    M.ecb_decrypt(st, keys, sk)
-    assert st.decrypt_to_u8(sk) == FIPS_PT
-    assert sk.stats["stages"] - 117 == 144
+    decrypts to the FIPS-197 Appendix B ciphertext; the inverse cipher (ecb.rs:34-50) takes 144 stages and returns the block.
+    With the re-association of unobservable xor chains (the default, as in the C++ mirror) the same gates take 99 / 135."""
+    for rebalance, enc_stages, dec_stages in ((False, 117, 144), (True, 99, 135)):
+        eng = M.ClearEngine()
+        sk = M.ServerKey(eng)
+        sk.set_xor_rebalance(rebalance)
+        keys = [M.Key.from_u8_enc(k, sk) for k in B.key_expansion_clear(FIPS_KEY)]
+        st = M.State.from_u8_enc(FIPS_PT, sk)
+        M.ecb_encrypt(st, keys, sk)
+        assert eng.stages == []                                   # nothing runs before the first decrypt
+        assert st.decrypt_to_u8(sk).hex() == FIPS_CT
+        assert (sk.stats["stages"], sk.stats["gates"]) == (enc_stages, 71824)
+        assert sum(2 if g["op"] == M.MUX else 1 for s in eng.stages for g in s) == 127872
+        if rebalance:   # MixColumns + AddRoundKey: three levels (496, 240, 128 bootstraps) instead of five (352, 128, 128, 128, 128)
+            assert [sum(2 if g["op"] == M.MUX else 1 for g in s) for s in eng.stages[:11]] == [128, 480, 3680, 3984, 2048, 1024, 512, 256, 496, 240, 128]
+        M.ecb_decrypt(st, keys, sk)
+        assert st.decrypt_to_u8(sk) == FIPS_PT
+        assert sk.stats["stages"] - enc_stages == dec_stages
+        assert sk.stats["gates"] - 71824 == 75604
     eng2, eager_key = eager()
     keys2 = [M.Key.from_u8_enc(k, eager_key) for k in B.key_expansion_clear(FIPS_KEY)]
     st2 = M.State.from_u8_enc(FIPS_PT, eager_key)
@@ -120,23 +126,77 @@ def test_recording_key_levels_one_block_like_the_host_mirror():
     assert len(eng2.stages) == 126 and st2.decrypt_to_u8(eager_key).hex() == FIPS_CT
 
 
+def test_xor_chain_rebalance_keeps_every_observable_value():
+    """rebalance_xor_chains on random circuits (boolean backend): xor / xnor chains with negated operands, intermediates
+    that are dropped, kept or shared by two consumers, ands and muxes in between.  Every kept handle reads the clear
+    evaluation, the gates are as many as recorded, every stage's gates read only slots written by earlier stages, and the
+    stages are fewer than without the re-association."""
+    import random
+    counts = {}
+    for rebalance in (False, True):
+        rnd = random.Random(4711)
+        stages = gates = 0
+        for trial in range(40):
+            eng = M.ClearEngine()
+            sk = M.ServerKey(eng)
+            sk.set_xor_rebalance(rebalance)
+            vals = [rnd.random() < 0.5 for _ in range(12)]
+            live = list(zip(sk.encrypt_many(vals), vals))
+            kept = []
+            for step in range(150):
+                pick = lambda: live[rnd.randrange(max(0, len(live) - 6), len(live))] if rnd.randrange(3) else live[rnd.randrange(len(live))]
+                a, b = pick(), pick()
+                if rnd.randrange(4) == 0:
+                    a = (M.not_(a[0]), not a[1])
+                kind = rnd.randrange(10)
+                z = sk.batch()
+                if kind < 6:
+                    op = M.XOR if rnd.randrange(4) else M.XNOR
+                    t, want = z.gate(op, a[0], b[0]), (a[1] != b[1]) == (op == M.XOR)
+                elif kind < 8:
+                    t, want = z.gate(M.AND, a[0], b[0]), a[1] and b[1]
+                else:
+                    c = pick()
+                    t, want = z.mux(c[0], a[0], b[0]), (a[1] if c[1] else b[1])
+                r = (z.run()[t], want)
+                del z
+                if rnd.randrange(5) == 0:
+                    kept.append(r)
+                live.append(r)
+                if len(live) > 14 and rnd.randrange(2):
+                    del live[rnd.randrange(12, len(live) - 1)]
+            kept.extend(live[12:])
+            del live, a, b, r
+            got = sk.decrypt_many([ct for ct, _ in kept])
+            assert got == [want for _, want in kept]
+            stages += sk.stats["stages"]
+            gates += sk.stats["gates"]
+        counts[rebalance] = (stages, gates)
+    assert counts[True][1] == counts[False][1]
+    assert counts[True][0] < counts[False][0]
+
+
 def test_two_ctr_blocks_share_stages():
     """modes/src/ctr.rs:26-35 unchanged on a recording key: the blocks' gates meet in the same stages, 118 for two blocks
-    (117 of ECB + the final xor), not 2 x 118; twice the gates of one block; SP 800-38A F.5.1 values."""
+    (117 of ECB + the final xor), not 2 x 118; twice the gates of one block; SP 800-38A F.5.1 values.  With the xor chains
+    re-associated (default) the final xor joins the last AddRoundKey's tree: 99 stages."""
     key = FIPS_KEY
     ctr0 = int("f0f1f2f3f4f5f6f7f8f9fafbfcfdfeff", 16)
     pts = [bytes.fromhex("6bc1bee22e409f96e93d7e117393172a"), bytes.fromhex("ae2d8a571e03ac9c9eb76fac45af8e51")]
     want = ["874d6191b620e3261bef6864990db6ce", "9806f66b7970fdff8617187bb9fffdff"]
-    eng = M.ClearEngine()
-    sk = M.ServerKey(eng)
-    keys = [M.Key.from_u8_enc(k, sk) for k in B.key_expansion_clear(key)]
-    counters = [M.State.from_u8_enc((ctr0 + b).to_bytes(16, "big"), sk) for b in range(2)]
-    states = [M.State.from_u8_enc(p, sk) for p in pts]
-    M.ctr_encrypt(counters, states, keys, sk)
-    assert [s.decrypt_to_u8(sk).hex() for s in states] == want
-    assert sk.stats["stages"] == 118 == len(eng.stages)
-    assert sk.stats["gates"] == 2 * (71824 + 128)
-    assert sk.stats["max_stage_width"] == 2 * 2128
+    for rebalance, n_stages in ((False, 118), (True, 99)):
+        eng = M.ClearEngine()
+        sk = M.ServerKey(eng)
+        sk.set_xor_rebalance(rebalance)
+        keys = [M.Key.from_u8_enc(k, sk) for k in B.key_expansion_clear(key)]
+        counters = [M.State.from_u8_enc((ctr0 + b).to_bytes(16, "big"), sk) for b in range(2)]
+        states = [M.State.from_u8_enc(p, sk) for p in pts]
+        M.ctr_encrypt(counters, states, keys, sk)
+        del counters
+        assert [s.decrypt_to_u8(sk).hex() for s in states] == want
+        assert sk.stats["stages"] == n_stages == len(eng.stages)
+        assert sk.stats["gates"] == 2 * (71824 + 128)
+        assert sk.stats["max_stage_width"] == 2 * 2128
 
 
 def test_online_key_expansion_takes_110_stages():

@@ -156,3 +156,32 @@ def test_modes_call_order_is_the_reference_one():
     assert enc == ["xor_key_enc", "sub_bytes", "shift_rows", "mix_columns", "xor_key_enc", "sub_bytes", "shift_rows", "xor_key_enc"]
     dec = re.findall(r"state\.(\w+)\(", py_fn(M.ecb_decrypt))
     assert dec == ["xor_key_enc", "inv_shift_rows", "inv_sub_bytes", "xor_key_enc", "inv_mix_columns", "inv_shift_rows", "inv_sub_bytes", "xor_key_enc"]
+
+
+def test_xor_chain_rebalance_is_the_same_procedure_on_both_sides():
+    """rebalance_xor_chains of hip.rs against the model's: the same absorption rule (xor / xnor, dead output slot, one use,
+    by an xor / xnor), the same parity (xnor, negation bits 0 and 1), the earliest-two-first merge with (level, arrival, slot)
+    ordering, spare slots popped for the inner gates, the root written to the original output with the parity in `neg`; and
+    Engine::flush applies it under the same condition as ServerKey.flush of the model."""
+    r = re.sub(r"\s+", "", rust_fn("hip.rs", "rebalance_xor_chains"))
+    p = re.sub(r"\s+", "", py_fn(M.rebalance_xor_chains))
+    # absorption rule, term by term and in the same order
+    assert "is_xor(&gates[i])&&is_dead[gates[i].outasusize]&&uses[i]==1&&is_xor(&gates[user[i]])" in r
+    assert 'is_xor(g)andg["out"]indeadanduses[i]==1andis_xor(gates[user[i]])' in p
+    # parity
+    assert "parity^=(x.op==sys::TFA_XNOR)asu32^(x.neg&1)^((x.neg>>1)&1)" in r
+    assert 'parity^=int(x["op"]==XNOR)^(x["neg"]&1)^((x["neg"]>>1)&1)' in p
+    # heap items (level, arrival, slot), inner gates on spare slots one level above the later operand, root on the gate's own output
+    assert "heap.push(Reverse((level[sasusize],seq,s)))" in r and "heap.append((level.get(s,0),len(heap),s))" in p
+    assert "(spare.pop().unwrap(),a.0.max(b.0)+1)" in r and "spare.pop(),max(a[0],b[0])+1" in p
+    assert "sys::tfa_gate{op:sys::TFA_XOR,in0:a.2,in1:b.2,in2:0,out:slot,neg:0}" in r
+    assert "dict(op=XOR,in0=a[2],in1=b[2],in2=0,out=slot,neg=0)" in p
+    assert "sys::tfa_gate{op:sys::TFA_XOR,in0:a.2,in1:b.2,in2:0,out:g.out,neg:parity},a.0.max(b.0)+1" in r
+    assert 'dict(op=XOR,in0=a[2],in1=b[2],in2=0,out=g["out"],neg=parity),max(a[0],b[0])+1' in p
+    assert r.count("whileheap.len()>2") == 1 and p.count("whilelen(heap)>2") == 1
+    # applied before the stages are submitted, only with pending gates, on the released list
+    f = re.sub(r"\s+", "", rust_fn("hip.rs", "flush"))
+    assert "ifself.xor_rebalance&&self.pending_gates>0{" in f and "rebalance_xor_chains(levels,&dead,self.next_freshasusize)" in f
+    assert f.index("rebalance_xor_chains") < f.index("tfa_stage_submit")
+    pf = re.sub(r"\s+", "", py_fn(M.ServerKey.flush))
+    assert "ifself.xor_rebalanceandself.pending_gates:" in pf and "rebalance_xor_chains(levels,set(self.released))" in pf

@@ -64,6 +64,11 @@ extern "C" int tfh_gen_keys(uint64_t seed, int device, tfh_keys **out) {
 extern "C" void tfh_keys_free(tfh_keys *k) { delete k; }
 extern "C" tfa_ctx *tfh_context(tfh_keys *k) { return k ? k->kp.server->context() : nullptr; }
 extern "C" int tfh_flush(tfh_keys *k) { TFH_TRY(k->kp.server->flush()) }
+extern "C" int tfh_set_xor_rebalance(tfh_keys *k, int on) {
+    if (!k) return TFA_EINVAL;
+    k->kp.server->set_xor_rebalance(on != 0);
+    return 0;
+}
 extern "C" int tfh_host_stats(tfh_keys *k, uint64_t out[4]) {
     ServerKeyStats s = k->kp.server->stats();
     out[0] = s.gates;

@@ -1,6 +1,8 @@
 #include "tfhe_boolean.h"
 
 #include <algorithm>
+#include <cstdlib>
+#include <functional>
 #include <stdexcept>
 
 namespace tfheaes {
@@ -87,6 +89,7 @@ ServerKey::ServerKey(const tfa_params &p, const uint32_t *bsk, const uint32_t *k
         ctx_ = nullptr;
         throw std::runtime_error("tfa_keys_upload failed: " + msg);
     }
+    if (const char *e = std::getenv("TFHE_AES_XOR_REBALANCE")) xor_rebalance_ = std::atoi(e) != 0;
     pool_slots_ = 1u << 17;  // 131072 slots = 424 MB: one AES block in flight (72 k slots) without a reallocation
     check(ctx_, tfa_pool_reserve(ctx_, pool_slots_), "tfa_pool_reserve");
 }
@@ -221,8 +224,110 @@ void ServerKey::upload_pending() {
     upload_words_.clear();
 }
 
+// Re-associates chains of xor / xnor gates whose intermediate results nobody can observe: an intermediate whose handle is gone
+// (its slot is on the deferred free list) and that feeds exactly one recorded gate, itself an xor / xnor.  Such a chain
+// x1 ^ x2 ^ ... ^ xn is one n-input parity: it is rebuilt with the same n - 1 xor gates, on the same slots, as the tree of least
+// depth for the levels at which its operands become available (the two earliest operands are combined first), and every
+// gate of the recording is levelled again.  MixColumns followed by AddRoundKey (state.rs:72-118, 217-224: five dependent xor
+// layers per output bit) becomes three levels.  Operand negations and xnors are gathered into one negation at the tree's root.
+// Gate counts, gate kinds and decrypted results do not change; set_xor_rebalance(false) keeps the recorded association.
+void ServerKey::rebalance_xor_chains() {
+    std::vector<tfa_gate> gates;
+    gates.reserve(pending_count_);
+    for (auto &lv : levels_) gates.insert(gates.end(), lv.begin(), lv.end());  // level order is a topological order
+    const size_t n = gates.size();
+    std::vector<int32_t> producer(next_fresh_, -1), user(n, -1);
+    std::vector<uint32_t> uses(n, 0), level(next_fresh_, 0);
+    std::vector<uint8_t> dead(next_fresh_, 0), absorbed(n, 0);
+    for (uint32_t s : deferred_free_) dead[s] = 1;
+    for (size_t i = 0; i < n; i++) producer[gates[i].out] = (int32_t)i;
+    auto operands = [](const tfa_gate &g) { return g.op == TFA_MUX ? 3 : 2; };
+    auto operand = [](const tfa_gate &g, int k) { return k == 0 ? g.in0 : k == 1 ? g.in1 : g.in2; };
+    auto is_xor = [](const tfa_gate &g) { return g.op == TFA_XOR || g.op == TFA_XNOR; };
+    for (size_t i = 0; i < n; i++)
+        for (int k = 0; k < operands(gates[i]); k++) {
+            const int32_t p = producer[operand(gates[i], k)];
+            if (p >= 0) {
+                uses[p]++;
+                user[p] = (int32_t)i;
+            }
+        }
+    bool any = false;
+    for (size_t i = 0; i < n; i++) {
+        absorbed[i] = is_xor(gates[i]) && dead[gates[i].out] && uses[i] == 1 && is_xor(gates[user[i]]);
+        any |= absorbed[i] != 0;
+    }
+    if (!any) return;
+    std::vector<std::vector<tfa_gate>> out;
+    auto put = [&](const tfa_gate &g, uint32_t lvl) {
+        if (out.size() < lvl) out.resize(lvl);
+        out[lvl - 1].push_back(g);
+        level[g.out] = lvl;
+    };
+    struct Item {
+        uint32_t level, seq, slot;
+        bool operator>(const Item &o) const { return level != o.level ? level > o.level : seq > o.seq; }
+    };
+    std::vector<Item> heap;
+    std::vector<uint32_t> spare, stack;
+    for (size_t i = 0; i < n; i++) {
+        if (absorbed[i]) continue;
+        const tfa_gate &g = gates[i];
+        bool root = false;
+        if (is_xor(g))
+            for (int k = 0; k < 2; k++) {
+                const int32_t p = producer[operand(g, k)];
+                root |= p >= 0 && absorbed[p];
+            }
+        if (!root) {
+            uint32_t lvl = 0;
+            for (int k = 0; k < operands(g); k++) lvl = std::max(lvl, level[operand(g, k)]);
+            put(g, lvl + 1);
+            continue;
+        }
+        heap.clear();
+        spare.clear();
+        stack.assign(1, (uint32_t)i);
+        uint32_t parity = 0, seq = 0;
+        while (!stack.empty()) {
+            const tfa_gate &x = gates[stack.back()];
+            stack.pop_back();
+            parity ^= (x.op == TFA_XNOR ? 1u : 0u) ^ (x.neg & 1u) ^ ((x.neg >> 1) & 1u);
+            for (int k = 0; k < 2; k++) {
+                const uint32_t s = operand(x, k);
+                const int32_t p = producer[s];
+                if (p >= 0 && absorbed[p]) {
+                    spare.push_back(s);
+                    stack.push_back((uint32_t)p);
+                } else {
+                    heap.push_back(Item{level[s], seq++, s});
+                }
+            }
+        }
+        std::make_heap(heap.begin(), heap.end(), std::greater<Item>());
+        auto pop = [&]() {
+            std::pop_heap(heap.begin(), heap.end(), std::greater<Item>());
+            Item it = heap.back();
+            heap.pop_back();
+            return it;
+        };
+        while (heap.size() > 2) {
+            const Item a = pop(), b = pop();
+            const uint32_t slot = spare.back(), lvl = std::max(a.level, b.level) + 1;
+            spare.pop_back();
+            put(tfa_gate{TFA_XOR, a.slot, b.slot, 0u, slot, 0u}, lvl);
+            heap.push_back(Item{lvl, seq++, slot});
+            std::push_heap(heap.begin(), heap.end(), std::greater<Item>());
+        }
+        const Item a = pop(), b = pop();
+        put(tfa_gate{TFA_XOR, a.slot, b.slot, 0u, g.out, parity}, std::max(a.level, b.level) + 1);
+    }
+    levels_.swap(out);
+}
+
 void ServerKey::flush() {
     upload_pending();
+    if (xor_rebalance_ && pending_count_ > 0) rebalance_xor_chains();
     for (auto &lv : levels_) {
         if (lv.empty()) continue;
         check(ctx_, tfa_stage_submit(ctx_, lv.data(), (uint32_t)lv.size()), "tfa_stage_submit");

@@ -89,6 +89,11 @@ class ServerKey {
 
     // Runs every recorded gate (level by level) and waits for the device.
     void flush();
+    // On (the default; TFHE_AES_XOR_REBALANCE=0 turns it off at construction): before a flush, chains of xor gates whose
+    // intermediate values have no live handle are re-associated into trees of least depth (same gates, same results, fewer
+    // stages; tfhe_boolean.cpp: rebalance_xor_chains).  Off: gates run in the association they were recorded in.
+    void set_xor_rebalance(bool on) { xor_rebalance_ = on; }
+    bool xor_rebalance() const { return xor_rebalance_; }
     // LWE words of an encrypted ciphertext (flushes first); used by ClientKey::decrypt and by gathers.
     std::vector<uint32_t> read(const Ciphertext &ct);
     void read_many(const std::vector<const Ciphertext *> &cts, uint32_t *out /*[count][n+1]*/);
@@ -114,6 +119,7 @@ class ServerKey {
     void release_slot(uint32_t slot);
     void upload_pending();
     void auto_flush();
+    void rebalance_xor_chains();
 
     tfa_params p_;
     tfa_ctx *ctx_ = nullptr;
@@ -122,6 +128,7 @@ class ServerKey {
     uint64_t epoch_ = 1;
     std::vector<std::vector<tfa_gate>> levels_;  // levels_[L-1] = gates at dependency level L
     uint64_t pending_count_ = 0;
+    bool xor_rebalance_ = true;
     std::vector<uint32_t> upload_slots_, upload_words_;
     ServerKeyStats stats_;
     std::shared_ptr<int> alive_;  // lets slot handles outlive the key safely

@@ -51,6 +51,10 @@ class Keys:
     def flush(self):
         _chk(_lib().tfh_flush(self.h), "tfh_flush")
 
+    def set_xor_rebalance(self, on):
+        """tfh_set_xor_rebalance: re-association of unobservable xor chains into least-depth trees before a flush (default on)"""
+        _chk(_lib().tfh_set_xor_rebalance(self.h, C.c_int(1 if on else 0)), "tfh_set_xor_rebalance")
+
     def host_stats(self):
         out = (C.c_uint64 * 4)()
         _lib().tfh_host_stats(self.h, out)

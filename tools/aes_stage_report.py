@@ -10,9 +10,9 @@ def width(r):
     if "pbs_lat" in name: return wgs, "lat"
     if "pbs_asm" in name or "pbs_kernel<" in name: return wgs * (wg // 64), "%dw" % (wg // 64)   # one bootstrap per wave
     return None, None
-# the timed block starts after the warm-up SubBytes: take the last 117 stages = everything after the 7th keyswitch
+# the timed block starts after the warm-up SubBytes (seven stages): everything after the 7th keyswitch
 ks_idx = [i for i, r in enumerate(rows) if "keyswitch" in r["Kernel_Name"] and "init" not in r["Kernel_Name"]]
-start = ks_idx[6] + 1 if len(ks_idx) > 117 else 0
+start = ks_idx[6] + 1 if len(ks_idx) > 7 else 0
 rows = rows[start:]
 t0, t1 = int(rows[0]["Start_Timestamp"]), int(rows[-1]["End_Timestamp"])
 busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows)
