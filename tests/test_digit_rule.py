@@ -36,7 +36,8 @@ def kernel_sequence(v, jj, acc):
 
 
 def asm_sequence(v, r, m, acc):
-    """the hand-scheduled loop's version (rotate_decompose in tools/pbs_asm/gen.py): negated accumulator in registers and
+    """the narrow-stage loops' version (tools/pbs_asm/lat_gen.py; the wide loop's until it took fp_sequence above, and still
+    its rotation addressing and sign handling: rotate_decompose in tools/pbs_asm/gen.py): negated accumulator in registers and
     rotation buffer, wrap / sign taken from one mask per lane; r = t - a, m = coefficient group, jj = r + 16 m"""
     n_src, n_own = np.uint32(0) - v.astype(np.uint32), np.uint32(0) - acc.astype(np.uint32)
     r = r.astype(np.uint32)
@@ -56,6 +57,39 @@ def asm_sequence(v, r, m, acc):
         nd1 = np.where(f >> np.uint32(9), f | np.uint32(0xFFFFFC00), f).astype(np.int32)
         d2 = (s - (u & np.uint32(0xFFFFFC00))).astype(np.int32)
     return -nd1.astype(np.int64), d2.astype(np.int64), idx
+
+
+def fp_sequence(x):
+    """the hand-scheduled wide loop's digits ("fp_digits" in tools/pbs_asm/gen.py): the biased, masked difference becomes the
+    low mantissa word of 2^52 + x, V = that double - (2^52 + 2^31 - 2^21) is the rounded difference in the window
+    [-2^31 + 2^21, 2^31 + 2^21), t = V (1 - 2^-21) + 1.5 * 2^74 rounds V to the nearest multiple of 2^22 with ties toward
+    zero (one IEEE rounding), and the loop keeps -d1 2^22 = 1.5 * 2^74 - t and d2 2^12 = V + that; x = sign * v - acc"""
+    with np.errstate(over="ignore"):
+        w = (x.astype(np.uint32) + np.uint32((0x800 + 0x80000000 - 0x200000) & 0xFFFFFFFF)) & np.uint32(0xFFFFF000)
+    d = (np.uint64(0x4330000000000000) | w.astype(np.uint64)).view(np.float64)
+    v = d - (2.0 ** 52 + 2.0 ** 31 - 2.0 ** 21)
+    m74 = 1.5 * 2.0 ** 74
+    t = v * (1.0 - 2.0 ** -21) + m74          # the product is exact (43 significant bits), so this is the fused result
+    neg_hi = m74 - t
+    lo = v + neg_hi
+    d1, d2 = -neg_hi / 2.0 ** 22, lo / 2.0 ** 12
+    assert (d1 == np.rint(d1)).all() and (d2 == np.rint(d2)).all()
+    return d1.astype(np.int64), d2.astype(np.int64)
+
+
+def test_fp_sequence_every_state():
+    """all 2^20 rounded states (with the discarded low bits at their extremes and around the rounding point), random words"""
+    hi = np.arange(1 << 20, dtype=np.uint64) << np.uint64(12)
+    for low in (0, 1, 0x7FF, 0x800, 0x801, 0xFFF):
+        x = ((hi + np.uint64(low)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        e1, e2 = literal_rule(x)
+        g1, g2 = fp_sequence(x)
+        assert (e1 == g1).all() and (e2 == g2).all()
+        assert g1.min() == -511 and g1.max() == 512 and g2.min() == -512 and g2.max() == 512
+    x = np.random.default_rng(13).integers(0, 1 << 32, 1 << 21, dtype=np.uint64).astype(np.uint32)
+    e1, e2 = literal_rule(x)
+    g1, g2 = fp_sequence(x)
+    assert (e1 == g1).all() and (e2 == g2).all()
 
 
 def test_asm_sequence():

@@ -27,7 +27,7 @@ WAVES = int(os.environ.get("PBS_ASM_WAVES", "8"))     # bootstraps per workgroup
 assert WAVES in (4, 8)
 ROWS_PER_WAVE = 16 // WAVES                          # LDS-DMA rows of a key chunk each wave fetches
 # schedule choices that can be switched off for measurement (PBS_ASM_OPT=comma list replaces the default set)
-OPT = set(f for f in os.environ.get("PBS_ASM_OPT", "mac_il,tw_spread,inv_split,lanesum,ls_pf2,wait_merge,dma_off").split(",") if f)
+OPT = set(f for f in os.environ.get("PBS_ASM_OPT", "mac_il,tw_spread,inv_split,lanesum,ls_pf2,wait_merge,dma_off,fp_digits").split(",") if f)
 # "lanesum": the sum over the four polynomials stays inside a lane.  After the second forward pass the four lanes of a quad
 # exchange frequency groups (in-place DPP moves) so that lane x holds, for ALL four polynomials and both levels, the four bins
 # whose high index digit is x; the products then accumulate in registers (no reduce-scatter of partial sums: 48 DPP moves and
@@ -35,6 +35,7 @@ OPT = set(f for f in os.environ.get("PBS_ASM_OPT", "mac_il,tw_spread,inv_split,l
 # transform must deliver its bins rotated by its polynomial number for that: the rotation is a factor i^(g t) on the inputs,
 # folded into the inter-pass twiddles, which the table therefore holds in all four quarter-turn rotations.
 LANESUM = "lanesum" in OPT
+FP_DIGITS = "fp_digits" in OPT
 K_TW_OFFSET = WAVES * (K_WAVE_LDS + K_A_BYTES)   # [exchange / rotation buffers][a_tilde arrays][twiddles][key ring]
 K_TW_ROW_BYTES = 1024 if LANESUM else 256       # twiddle table [element][t]: 16 bytes each, or 4 rotations x 16 bytes
 K_RING_OFFSET = K_TW_OFFSET + 16 * K_TW_ROW_BYTES
@@ -42,6 +43,19 @@ K_CHUNK_BYTES = 16384
 K_LDS_BYTES = K_RING_OFFSET + 4 * K_CHUNK_BYTES
 STEP_KEY_BYTES = 131072
 MAGIC = 6755399441055744.0  # 1.5 * 2^52
+# "fp_digits": both digits of a coefficient come out of four fp64 instructions instead of seven integer ones and two
+# conversions.  x = (sign * acc[src] - acc + 2^11 + 2^31 - 2^21) & ~0xfff is written into the low word of a register pair whose
+# high word holds 0x43300000, so the pair reads as the double 2^52 + x; V = pair - (2^52 + 2^31 - 2^21) is the rounded
+# difference as a signed multiple of 2^12 in [-2^31 + 2^21, 2^31 + 2^21), the window in which the top digit is the tfhe-rs
+# one, [-511, 512].  The low digit's rule (carry when the residue exceeds B/2, or equals B/2 and the state's top bit is set) is
+# "nearest multiple of 2^22, ties toward zero" on V: t = V (1 - 2^-21) + 1.5 * 2^74 (exact product, one rounding at a unit of
+# 2^22; the factor moves a tie by at least 1 and nothing by 2^12 or more), d1 2^22 = t - 1.5 * 2^74, d2 2^12 = V - d1 2^22, all
+# exact.  The key of the lane-local-sum layout carries the factors 2^-22 / 2^-12 (exact scalings: same rounded results).
+DIGIT_BIAS = (0x800 + 0x80000000 - 0x200000) & 0xFFFFFFFF
+DIGIT_K = 2.0 ** 52 + 2.0 ** 31 - 2.0 ** 21
+DIGIT_C = 1.0 - 2.0 ** -21
+MAGIC74 = 1.5 * 2.0 ** 74
+KEY_SCALE = (2.0 ** -22, 2.0 ** -12)      # per level, folded into the key by its layout kernel when FP_DIGITS
 
 
 def kperm(p):
@@ -77,6 +91,7 @@ V_TWF = 13                       # lanesum: twiddle row address with this lane's
 V_AREAD = 19                     # next step's rotation amount (u16 read from LDS)
 V_SCR = list(range(20, 30))      # scratch ints; also v[20:21], v[22:23] as fp64 scratch of the twiddle products
 V_MAGIC = 30                     # v[30:31] = 1.5 * 2^52
+V_MAGIC74 = 14                   # v[14:15] = 1.5 * 2^74 (fp_digits: rounds to multiples of 2^22)
 V_ACC = 32
 R_A, R_B, R_K, R_T = 64, 128, 192, 224
 
@@ -382,6 +397,10 @@ class Loop:
                 e("v_bfe_i32 v%d, v%d, %d, 1" % (tmp, fw, m))
                 e("v_lshl_add_u32 v%d, v%d, 13, v%d" % (tmp, tmp, a0))      # a0 - 8192 once wrapped
             e("ds_read_b32 v%d, v%d offset:%d" % (R_K + m, tmp, 256 * m))
+        if FP_DIGITS:
+            assert LANESUM, "the key scaling of fp_digits lives in the lane-local-sum layout"
+            self.digits_fp(fs)
+            return
         # the m-th read has returned when at most 31 - m younger ones are in flight (the counter saturates at 15)
         sg, c, y, s_, u, w = V_SCR[3], V_SCR[4], V_SCR[5], V_SCR[6], V_SCR[7], V_SCR[8]
         for m in range(32):
@@ -414,6 +433,67 @@ class Loop:
             e("v_sub_u32 v%d, v%d, v%d" % (u, s_, u))                    # d2
             e("v_cvt_f64_i32 %s, v%d" % (dreg(R_B + 2 * m), u))
 
+    def digits_fp(self, fs):
+        """digits of the 32 rotated coefficients in R_K (see FP_DIGITS above), four coefficients at a time so that no
+        instruction follows the one it depends on; array A <- -d1 2^22, array B <- d2 2^12"""
+        e = self.e
+        G_ = int(os.environ.get("PBS_ASM_FPG", "0"))
+        if G_:
+            # measurement variant: groups of G_ coefficients, no temporaries for the doubles: the pair (x, 0x43300000) is array B's
+            # slot itself (its high word written per coefficient), V replaces it in place, t sits in array A's slot
+            sg = [R_T + j for j in range(G_)]
+            cy = [R_T + 16 + j for j in range(G_)]
+            kreg, creg = self.consts.get(DIGIT_K), self.consts.get(DIGIT_C)
+            for m0 in range(0, 32, G_):
+                ms = range(m0, m0 + G_)
+                for j, m in enumerate(ms):
+                    self.lds_wait(min(15, 31 - m))
+                    e("v_bfe_i32 v%d, v%d, %d, 1" % (sg[j], fs, m))
+                    e("v_bfe_u32 v%d, v%d, %d, 1" % (cy[j], fs, m))
+                for j, m in enumerate(ms):
+                    e("v_add3_u32 v%d, v%d, v%d, s%d" % (cy[j], cy[j], V_ACC + m, S_C2048))
+                for j, m in enumerate(ms):
+                    e("v_xad_u32 v%d, v%d, v%d, v%d" % (cy[j], R_K + m, sg[j], cy[j]))
+                for j, m in enumerate(ms):
+                    e("v_and_b32 v%d, s%d, v%d" % (R_B + 2 * m, S_C511, cy[j]))
+                    e("v_mov_b32 v%d, 0x43300000" % (R_B + 2 * m + 1))
+                for m in ms:
+                    e("v_add_f64 %s, %s, -%s" % (dreg(R_B + 2 * m), dreg(R_B + 2 * m), kreg))
+                for m in ms:
+                    e("v_fma_f64 %s, %s, %s, %s" % (dreg(R_A + 2 * m), dreg(R_B + 2 * m), creg, dreg(V_MAGIC74)))
+                for m in ms:
+                    e("v_add_f64 %s, %s, -%s" % (dreg(R_A + 2 * m), dreg(V_MAGIC74), dreg(R_A + 2 * m)))
+                for m in ms:
+                    e("v_add_f64 %s, %s, %s" % (dreg(R_B + 2 * m), dreg(R_B + 2 * m), dreg(R_A + 2 * m)))
+            return
+        D = [R_T + 2 * j for j in range(4)]              # (x, 0x43300000) pairs
+        Vv = [R_T + 8 + 2 * j for j in range(4)]
+        Tt = [R_T + 16 + 2 * j for j in range(4)]
+        sg = [R_T + 24 + j for j in range(4)]
+        cy = [R_T + 28 + j for j in range(4)]
+        for j in range(4):
+            e("v_mov_b32 v%d, 0x43300000" % (D[j] + 1))
+        kreg, creg = self.consts.get(DIGIT_K), self.consts.get(DIGIT_C)
+        for m0 in range(0, 32, 4):
+            for j in range(4):
+                self.lds_wait(min(15, 31 - (m0 + j)))
+                e("v_bfe_i32 v%d, v%d, %d, 1" % (sg[j], fs, m0 + j))
+                e("v_bfe_u32 v%d, v%d, %d, 1" % (cy[j], fs, m0 + j))
+            for j in range(4):
+                e("v_add3_u32 v%d, v%d, v%d, s%d" % (cy[j], cy[j], V_ACC + m0 + j, S_C2048))
+            for j in range(4):
+                e("v_xad_u32 v%d, v%d, v%d, v%d" % (cy[j], R_K + m0 + j, sg[j], cy[j]))
+            for j in range(4):
+                e("v_and_b32 v%d, s%d, v%d" % (D[j], S_C511, cy[j]))
+            for j in range(4):
+                e("v_add_f64 %s, %s, -%s" % (dreg(Vv[j]), dreg(D[j]), kreg))
+            for j in range(4):
+                e("v_fma_f64 %s, %s, %s, %s" % (dreg(Tt[j]), dreg(Vv[j]), creg, dreg(V_MAGIC74)))
+            for j in range(4):
+                e("v_add_f64 %s, %s, -%s" % (dreg(R_A + 2 * (m0 + j)), dreg(V_MAGIC74), dreg(Tt[j])))
+            for j in range(4):
+                e("v_add_f64 %s, %s, %s" % (dreg(R_B + 2 * (m0 + j)), dreg(Vv[j]), dreg(R_A + 2 * (m0 + j))))
+
     # ---- twiddles -------------------------------------------------------------------------------------------------------
     def tw_issue(self, k0, count, region):
         for k in range(count):
@@ -423,14 +503,23 @@ class Loop:
     def tw_mul(self, X, k0, count, region, S):
         """X[k0 .. k0+count) *= (c + i S s) in place, entry j of `region` = (c, s) of element k0 + j"""
         e = self.e
-        m1, m2 = V(V_SCR[0]), V(V_SCR[2])
-        for j in range(count):
-            c, s = V(region + 4 * j), V(region + 4 * j + 2)
-            z = X.val(k0 + j)
-            e("v_mul_f64 %s, %s, %s" % (dreg(m1.reg), z.i.s(), s.s()))
-            e("v_mul_f64 %s, %s, %s" % (dreg(m2.reg), z.r.s(), s.s()))
-            e("v_fma_f64 %s, %s, %s, %s" % (dreg(z.r.reg), z.r.s(), c.s(), m1.s(flip=S > 0)))
-            e("v_fma_f64 %s, %s, %s, %s" % (dreg(z.i.reg), z.i.s(), c.s(), m2.s(flip=S < 0)))
+        # "tw_il": two elements at a time on two pairs of scratch registers, so that a multiply-add follows the product it
+        # consumes by four instructions instead of two
+        width = 2 if "tw_il" in OPT else 1
+        assert count % width == 0
+        for j0 in range(0, count, width):
+            muls, fmas = [], []
+            for w in range(width):
+                j = j0 + w
+                m1, m2 = V(V_SCR[4 * w]), V(V_SCR[4 * w + 2])
+                c, s = V(region + 4 * j), V(region + 4 * j + 2)
+                z = X.val(k0 + j)
+                muls.append("v_mul_f64 %s, %s, %s" % (dreg(m1.reg), z.i.s(), s.s()))
+                muls.append("v_mul_f64 %s, %s, %s" % (dreg(m2.reg), z.r.s(), s.s()))
+                fmas.append("v_fma_f64 %s, %s, %s, %s" % (dreg(z.r.reg), z.r.s(), c.s(), m1.s(flip=S > 0)))
+                fmas.append("v_fma_f64 %s, %s, %s, %s" % (dreg(z.i.reg), z.i.s(), c.s(), m2.s(flip=S < 0)))
+            for ln in muls + fmas:
+                e(ln)
 
     def tw_mul_first(self, X, count, region, scratch):
         """Phase 1 of X[k] *= (c - i s) (the inverse transform's twiddles), from the real parts alone:
@@ -750,22 +839,34 @@ class Loop:
         # untwist by e^{-i pi n1 / 32}, round to the torus, accumulate, and put the new accumulator into the rotation buffer
         st = Stream(self, self.pool)
         magic = V(V_MAGIC)
-        for n1 in range(16):
-            z = A.val(n1)
-            if n1 == 0:
-                rr, ri = st.add(z.r, magic), st.add(z.i, magic)
-            else:
-                tau, c = KS32[n1] / KC32[n1], KC32[n1]
-                nr = st.fmac(tau, z.i, z.r)          # (r + i i)(1 - i tau)
-                ni = st.fmac(-tau, z.r, z.i)
-                # round(c x) as an integer in the low mantissa word: one multiply-add with 1.5 * 2^52
-                rr, ri = st.fmac(c, nr, magic), st.fmac(c, ni, magic)
-                st.kill(nr, ni)
-            for (val, m) in ((rr, n1), (ri, 16 + n1)):
-                st.e("v_sub_u32 v%d, v%d, v%d" % (V_ACC + m, V_ACC + m, val.reg))      # the negated accumulator
-                # buffer word 4 (16 m + t) + g = 64 m + lane: the store needs no address register
-                st.e("ds_write_addtid_b32 v%d offset:%d" % (V_ACC + m, 256 * m))
-            st.kill(rr, ri)
+        # "tail_il": two elements at a time, stage by stage (untwist, scale and round, accumulate, store), so that no
+        # instruction follows the one it depends on by fewer than four
+        width = 2 if "tail_il" in OPT else 1
+        for n0 in range(0, 16, width):
+            zs = [A.val(n1) for n1 in range(n0, n0 + width)]
+            rot = []
+            for n1, z in zip(range(n0, n0 + width), zs):
+                if n1 == 0:
+                    rot.append(None)
+                else:
+                    tau = KS32[n1] / KC32[n1]
+                    rot.append((st.fmac(tau, z.i, z.r), st.fmac(-tau, z.r, z.i)))      # (r + i i)(1 - i tau)
+            rnd = []
+            for n1, z, nrni in zip(range(n0, n0 + width), zs, rot):
+                if nrni is None:
+                    rnd.append((st.add(z.r, magic), st.add(z.i, magic)))
+                else:
+                    # round(c x) as an integer in the low mantissa word: one multiply-add with 1.5 * 2^52
+                    rnd.append((st.fmac(KC32[n1], nrni[0], magic), st.fmac(KC32[n1], nrni[1], magic)))
+                    st.kill(*nrni)
+            for n1, (rr, ri) in zip(range(n0, n0 + width), rnd):
+                for (val, m) in ((rr, n1), (ri, 16 + n1)):
+                    st.e("v_sub_u32 v%d, v%d, v%d" % (V_ACC + m, V_ACC + m, val.reg))      # the negated accumulator
+            for n1, (rr, ri) in zip(range(n0, n0 + width), rnd):
+                for m in (n1, 16 + n1):
+                    # buffer word 4 (16 m + t) + g = 64 m + lane: the store needs no address register
+                    st.e("ds_write_addtid_b32 v%d offset:%d" % (V_ACC + m, 256 * m))
+                st.kill(rr, ri)
         self.out.extend(st.ins)
         assert len(self.pool.free) == 16
         # M0 is shared with the ring's LDS-DMA (acquire() sets it before each of its loads): point it at the rotation
@@ -778,10 +879,28 @@ class Loop:
         body = Loop.__new__(Loop)
         body.consts, body.out, body.pool = self.consts, [], self.pool
         body.step()
+        # measurement only (PBS_ASM_PAD=class:count): `count` harmless extra instructions of one class spread evenly over the
+        # step (they write registers nothing reads, so the results stay bit-exact): what one more instruction of that class
+        # costs inside this loop
+        pad = os.environ.get("PBS_ASM_PAD", "")
+        if pad:
+            kind, count = pad.split(":")
+            count = int(count)
+            forms = {"f64": ["v_add_f64 v[%d:%d], v[30:31], v[30:31]" % (r, r + 1) for r in (24, 26, 28)],
+                     "fma": ["v_fma_f64 v[%d:%d], v[30:31], v[30:31], v[30:31]" % (r, r + 1) for r in (24, 26, 28)],
+                     "int": ["v_bfe_i32 v%d, v3, 2, 1" % r for r in (24, 25, 26)],
+                     "short": ["v_add_u32 v%d, v3, v3" % r for r in (24, 25, 26)],
+                     "dpp": ["v_mov_b32_dpp v%d, v3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" % r for r in (24, 25, 26)],
+                     "lds": ["ds_read_b32 v%d, v17" % r for r in (24, 25, 26)],
+                     "salu": ["s_add_u32 s97, s97, 1"] * 3}[kind]
+            valu_at = [i for i, ln in enumerate(body.out) if ln.startswith("v_")]
+            picks = [valu_at[(2 * k + 1) * len(valu_at) // (2 * count)] for k in range(count)]
+            for k, at in reversed(list(enumerate(picks))):
+                body.out.insert(at, forms[k % 3])
         # constants (known only after the body has been generated)
         import struct
-        e("s_mov_b32 s%d, 0x800" % S_C2048)
-        e("s_mov_b32 s%d, 0x1ff" % S_C511)
+        e("s_mov_b32 s%d, 0x%x" % (S_C2048, DIGIT_BIAS if FP_DIGITS else 0x800))
+        e("s_mov_b32 s%d, 0x%x" % (S_C511, 0xfffff000 if FP_DIGITS else 0x1ff))
         e("v_readfirstlane_b32 s%d, v%d" % (S_ROTM0, V_ROTBASE))       # lane 0: g = 0, the buffer's first byte
         for j, val in enumerate(self.consts.vals):
             bits = struct.unpack("<Q", struct.pack("<d", val))[0]
@@ -790,8 +909,14 @@ class Loop:
         mbits = struct.unpack("<Q", struct.pack("<d", MAGIC))[0]
         e("v_mov_b32 v%d, 0x%x" % (V_MAGIC, mbits & 0xFFFFFFFF))
         e("v_mov_b32 v%d, 0x%x" % (V_MAGIC + 1, mbits >> 32))
+        if FP_DIGITS:
+            mbits = struct.unpack("<Q", struct.pack("<d", MAGIC74))[0]
+            e("v_mov_b32 v%d, 0x%x" % (V_MAGIC74, mbits & 0xFFFFFFFF))
+            e("v_mov_b32 v%d, 0x%x" % (V_MAGIC74 + 1, mbits >> 32))
         if "dma_off" in OPT:
             e("v_add_u32 v%d, 0x%x, v%d" % (V_KADDR, K_RING_OFFSET, V_KBASE))
+        if "shift4" in OPT:      # measurement: the loop's instruction stream moved by four bytes (placement sensitivity)
+            e("s_nop 0")
         e("L_step%=:")
         self.out.extend(place_waits(body.out) if AUTO_WAITS else body.out)
         e("s_add_u32 s%d, s%d, 0x%x" % (S_KP, S_KP, STEP_KEY_BYTES))
@@ -903,13 +1028,26 @@ def experiment_filter(lines, flags):
     """Timing experiments (results become garbage): drop classes of instructions from the emitted loop.
     nolds: every ds_* instruction; nokey / notw / noexch / norot: the key, twiddle, exchange, rotation LDS traffic; nowait: the LDS waits; nobar: the barriers; nodma: the ring's LDS-DMA and its waits."""
     out = []
+    tw_seen = 0
     for ln in lines:
         op = ln.split()[0]
+        # rotation addressing / sign handling of the decomposition removed (what a wrap-free, pre-signed rotation buffer would save)
+        if "noaddr" in flags and op == "v_lshl_add_u32" and ", 13, " in ln:
+            continue
+        if "noaddr" in flags and op == "v_bfe_i32" and ln.endswith(", 1") and ", v%d, " % V_SCR[0] in ln and "v%d," % V_SCR[3] in ln:
+            continue
+        if "nosign" in flags and op in ("v_bfe_i32", "v_bfe_u32") and ", v%d, " % V_SCR[1] in ln:
+            continue
+        if "nosign" in flags and op == "v_xad_u32":
+            continue
+        if "notw48" in flags and op == "v_mul_f64" and ("v[%d:%d]," % (V_SCR[0], V_SCR[0] + 1) in ln) and tw_seen < 48:
+            tw_seen += 1      # one product of each of 48 inter-pass twiddle multiplications (what folding them into butterflies would save)
+            continue
         if "nolds" in flags and op.startswith("ds_"):
             continue
         if "nokey" in flags and op == "ds_read_b128" and ", v%d " % V_KADDR in ln:
             continue
-        if "notw" in flags and op == "ds_read_b128" and ", v%d " % V_TW in ln:
+        if "notw" in flags and op == "ds_read_b128" and (", v%d " % V_TW in ln or ", v%d " % V_TWF in ln):
             continue
         if "twlane" in flags and op == "ds_read_b128" and ", v%d " % V_TW in ln:
             ln = ln.replace(", v%d " % V_TW, ", v%d " % V_LANE16)     # one distinct 16-byte word per lane instead of one per four lanes
@@ -948,6 +1086,8 @@ def main():
             f.write('    "%s\\n\\t" \\\n' % ln)
         f.write('    ""\n')
         f.write("#define TFA_PBS_ASM%s_CLOBBERS %s\n" % ("" if WAVES == 8 else "4", ", ".join(cl + ['"memory"', '"scc"', '"vcc"'])))
+        # what the loop expects of the key: the per-level power-of-two factors its digits carry (1, 1 without fp_digits)
+        f.write("#define TFA_PBS_ASM%s_KEY_SCALE_LOG2 %d, %d\n" % ("" if WAVES == 8 else "4", *((-22, -12) if FP_DIGITS else (0, 0))))
     stats = {}
     for ln in lines:
         op = ln.split()[0]
