@@ -132,7 +132,8 @@ class Machine:
                             self.v[r0 + k] = wd
                 continue
             if op == "s_barrier":
-                assert not any(item is not None and item[2] for item in self.lds_queue), "key reads in flight at a barrier: " + str(pc)
+                if G.RING_AHEAD == 3:     # the slot refilled after this barrier is the one the youngest key reads came from
+                    assert not any(item is not None and item[2] for item in self.lds_queue), "key reads in flight at a barrier: " + str(pc)
                 continue
             if op == "s_nop":
                 continue
@@ -230,7 +231,7 @@ class Machine:
                     b = self.lds_read(addr, n).reshape(W, L, n // 4, 4).astype(np.uint32)
                     words = b[..., 0] | (b[..., 1] << 8) | (b[..., 2] << 16) | (b[..., 3] << 24)
                     r0 = int(re.match(r"v\[?(\d+)", dst).group(1))
-                    self.lds_queue.append((r0, [words[..., k].copy() for k in range(n // 4)], addr_tok == "v%d" % G.V_KADDR))
+                    self.lds_queue.append((r0, [words[..., k].copy() for k in range(n // 4)], addr_tok == "v%d" % G.V_KADDR, (int(addr.min()), int(addr.max()) + n)))
                     continue
             elif op in ("ds_write_b32", "ds_write_b64", "ds_write_b128"):
                 addr_tok, data_tok = a[0], a[1].split()[0]
@@ -285,6 +286,9 @@ class Machine:
                 src = base[:, None] + voff + off
                 data = self.key[src[..., None] + np.arange(16)]
                 dst = self.m0.astype(np.int64)[:, None] + off + np.arange(L) * 16
+                lo_, hi_ = int(dst.min()), int(dst.max()) + 16
+                for item in self.lds_queue:      # (the waves run in lock step here, so this also covers the other waves' reads)
+                    assert item is None or len(item) < 4 or item[3][1] <= lo_ or item[3][0] >= hi_, "LDS-DMA into a slot with reads in flight: line %d" % pc
                 self.dma_queue.append((dst[..., None] + np.arange(16), data))
             else:
                 raise NotImplementedError(ln)
@@ -383,8 +387,8 @@ def main():
         M.s[G.S_ACUR][w] = al + 2
         M.s[G.S_A][w] = a_tilde[w, 0]
         M.s[G.S_M0ROW][w] = G.K_RING_OFFSET + r0 * 1024
-        # chunks 0, 1, 2 of step 0 are already on their way when the loop starts
-        for ch in range(3):
+        # the first chunks of step 0 (as many as the loop keeps ahead) are already on their way when the loop starts
+        for ch in range(G.RING_AHEAD):
             for row in range(r0, r0 + rpw):
                 src = kw + ch * (G.K_CHUNK_BYTES if G.LANESUM else 8192) + (row - r0) * 1024
                 dst = G.K_RING_OFFSET + ch * G.K_CHUNK_BYTES + row * 1024

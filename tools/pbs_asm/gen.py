@@ -27,7 +27,7 @@ WAVES = int(os.environ.get("PBS_ASM_WAVES", "8"))     # bootstraps per workgroup
 assert WAVES in (4, 8)
 ROWS_PER_WAVE = 16 // WAVES                          # LDS-DMA rows of a key chunk each wave fetches
 # schedule choices that can be switched off for measurement (PBS_ASM_OPT=comma list replaces the default set)
-OPT = set(f for f in os.environ.get("PBS_ASM_OPT", "mac_il,tw_spread,inv_split,lanesum,ls_pf2,wait_merge,dma_off,fp_digits").split(",") if f)
+OPT = set(f for f in os.environ.get("PBS_ASM_OPT", "mac_il,tw_spread,inv_split,lanesum,ls_pf2,wait_merge,dma_off,fp_digits,ring2").split(",") if f)
 # "lanesum": the sum over the four polynomials stays inside a lane.  After the second forward pass the four lanes of a quad
 # exchange frequency groups (in-place DPP moves) so that lane x holds, for ALL four polynomials and both levels, the four bins
 # whose high index digit is x; the products then accumulate in registers (no reduce-scatter of partial sums: 48 DPP moves and
@@ -35,6 +35,10 @@ OPT = set(f for f in os.environ.get("PBS_ASM_OPT", "mac_il,tw_spread,inv_split,l
 # transform must deliver its bins rotated by its polynomial number for that: the rotation is a factor i^(g t) on the inputs,
 # folded into the inter-pass twiddles, which the table therefore holds in all four quarter-turn rotations.
 LANESUM = "lanesum" in OPT
+# "ring2": a chunk's barrier is followed by the load of the chunk TWO ahead, into the slot of the chunk two back (whose every
+# read has been consumed by then), instead of three ahead into the slot of the previous chunk: the key reads still in flight at
+# a barrier (the previous chunk's last words) then need not be drained in front of it.
+RING_AHEAD = 2 if "ring2" in OPT else 3
 FP_DIGITS = "fp_digits" in OPT
 K_TW_OFFSET = WAVES * (K_WAVE_LDS + K_A_BYTES)   # [exchange / rotation buffers][a_tilde arrays][twiddles][key ring]
 K_TW_ROW_BYTES = 1024 if LANESUM else 256       # twiddle table [element][t]: 16 bytes each, or 4 rotations x 16 bytes
@@ -566,9 +570,9 @@ class Loop:
         """chunk q of the current step: own DMA rows landed, barrier, refill the slot freed by the previous chunk with
         chunk q + 3 (the key buffer is padded, so the prefetch needs no end-of-key test), key read address of chunk q"""
         e = self.e
-        e("s_waitcnt vmcnt(%d)" % (2 * ROWS_PER_WAVE))       # own rows of chunk q: at most the two younger chunks' rows stay in flight
+        e("s_waitcnt vmcnt(%d)" % ((RING_AHEAD - 1) * ROWS_PER_WAVE))       # own rows of chunk q: only the younger chunks' rows stay in flight
         e("s_barrier")
-        qq = q + 3
+        qq = q + RING_AHEAD
         if LANESUM:      # the key is stored in the order the ring takes it: [step][chunk][row][lane]
             off = qq * K_CHUNK_BYTES if qq < 8 else STEP_KEY_BYTES + (qq - 8) * K_CHUNK_BYTES
         else:
@@ -689,30 +693,46 @@ class Loop:
         return [R_K, R_K + 16, R_T + 16] if "ls_pf2" in OPT else [R_K, R_K + 16]
 
     def key_issue_ls(self, lv, j, buf):
-        """key words [j][j' = 0..3] of the chunk (k_lo, lv) at hand, into key buffer `buf`"""
+        """key words [j][j' = 0..3] of the chunk (k_lo, lv) at hand, into key buffer `buf` (first register of sixteen, or a list
+        of four aligned register quads)"""
         base = self.ring_slot * K_CHUNK_BYTES if "dma_off" in OPT else 0
+        quads = buf if isinstance(buf, list) else [buf + 4 * jp for jp in range(4)]
         for jp in range(4):
-            self.e("ds_read_b128 %s, v%d offset:%d" % (qreg(buf + 4 * jp), V_KADDR, base + (4 * j + jp) * 1024))
+            self.e("ds_read_b128 %s, v%d offset:%d" % (qreg(quads[jp]), V_KADDR, base + (4 * j + jp) * 1024))
 
     def mac_lanesum(self, A, B):
         """A[position (k_lo, j')] <- sum over levels and slot sets j of spectrum[lv][(k_lo, j)] x key[k_lo][lv][j][j'].  Eight
         independent accumulation chains per bin (four output slots, real and imaginary), sixteen multiply-adds each; a term's
         four key words are fetched one (two with ls_pf2) terms ahead, under the products.  Chunk (k_lo, lv) of the ring = the
-        sixteen key words [j][j'] of one level of one bin."""
+        sixteen key words [j][j'] of one level of one bin.  "ls_pf3": from the second bin on a fourth buffer (the level-2
+        slots of the first bin, consumed by then) lets the words travel three terms ahead."""
         T = [R_T + 2 * n for n in range(8)]
         pr, pi = T[0:4], T[4:8]
-        bufs = self.key_buffers()
-        ahead = len(bufs) - 1
+        free = [[b + 4 * jp for jp in range(4)] for b in self.key_buffers()]
         terms = [(k_lo, lv, j) for k_lo in range(4) for lv in (0, 1) for j in range(4)]
-        # chunk 0 was acquired and the first `ahead` terms' words requested inside the second forward pass (see step())
+        # chunk 0 was acquired and the first terms' words requested inside the second forward pass (see step())
+        held, issued = {}, len(free) - 1
+        for n in range(issued):
+            held[n] = free.pop(0)
         for n, (k_lo, lv, j) in enumerate(terms):
             X = A if lv == 0 else B
             f = X.val_at(4 * k_lo + j)
             if lv == 0:
                 f = C(-f.r, -f.i)                 # array A is the spectrum of the NEGATED level-1 digits
             first, last = (lv, j) == (0, 0), (lv, j) == (1, 3)
-            buf = bufs[n % len(bufs)]
-            key = [(V(buf + 4 * jp), V(buf + 4 * jp + 2)) for jp in range(4)]
+            if "ls_pf3" in OPT and n == 8:        # array B's first four positions have been consumed
+                free.append([R_B, R_B + 4, R_B + 32, R_B + 36])
+            # the key words of the terms ahead travel under this term's products; a new chunk is acquired first
+            nxt = []
+            while issued < len(terms) and free:
+                nk, nlv, nj = terms[issued]
+                if nj == 0:
+                    nxt += self.capture(self.acquire, 2 * nk + nlv)
+                held[issued] = free.pop(0)
+                nxt += self.capture(self.key_issue_ls, nlv, nj, held[issued])
+                issued += 1
+            quads = held.pop(n)
+            key = [(V(quads[jp]), V(quads[jp] + 2)) for jp in range(4)]
             ins = []
             for part in (0, 1):                   # part 0: products with the real part of the spectrum, part 1: imaginary
                 for jp in range(4):
@@ -729,14 +749,8 @@ class Loop:
                     else:
                         ins.append("v_fma_f64 %s, %s, %s, %s" % (dr, f.i.s(flip=True), y.s(), dreg(pr[jp])))
                         ins.append("v_fma_f64 %s, %s, %s, %s" % (di, f.i.s(), x.s(), dreg(pi[jp])))
-            # the key words of the term `ahead` terms on travel under this term's products; a new chunk is acquired first
-            nxt = []
-            if n + ahead < len(terms):
-                nk, nlv, nj = terms[n + ahead]
-                if nj == 0:
-                    nxt += self.capture(self.acquire, 2 * nk + nlv)
-                nxt += self.capture(self.key_issue_ls, nlv, nj, bufs[(n + ahead) % len(bufs)])
             self.out.extend(self.spread(ins, nxt) if "mac_il" in OPT else ins + nxt)
+            free.append(quads)
 
     # ---- the step ---------------------------------------------------------------------------------------------------------
     def capture(self, fn, *args):
@@ -973,7 +987,7 @@ def place_waits(lines):
         touched = touched_at[pos]
         need = -1
         for k, (dst, is_key, _) in enumerate(queue):
-            if (dst & touched) or (is_key and op == "s_barrier"):
+            if (dst & touched) or (is_key and op == "s_barrier" and RING_AHEAD == 3):
                 need = k
         if op == "s_cbranch_scc1" or "vmcnt(0) lgkmcnt(0)" in ln:
             need = max([k for k, q in enumerate(queue) if q[0]], default=-1)
@@ -1061,7 +1075,7 @@ def experiment_filter(lines, flags):
             continue
         if "nobar" in flags and op == "s_barrier":
             continue
-        if "nodma" in flags and (op.startswith("global_load_lds") or (op == "s_waitcnt" and ln.strip() == "s_waitcnt vmcnt(%d)" % (2 * ROWS_PER_WAVE))):
+        if "nodma" in flags and (op.startswith("global_load_lds") or (op == "s_waitcnt" and ln.strip() == "s_waitcnt vmcnt(%d)" % ((RING_AHEAD - 1) * ROWS_PER_WAVE))):
             continue
         out.append(ln)
     return out
@@ -1087,6 +1101,7 @@ def main():
         f.write('    ""\n')
         f.write("#define TFA_PBS_ASM%s_CLOBBERS %s\n" % ("" if WAVES == 8 else "4", ", ".join(cl + ['"memory"', '"scc"', '"vcc"'])))
         # what the loop expects of the key: the per-level power-of-two factors its digits carry (1, 1 without fp_digits)
+        f.write("#define TFA_PBS_ASM%s_RING_AHEAD %d\n" % ("" if WAVES == 8 else "4", RING_AHEAD))      # chunks in flight when the loop starts
         f.write("#define TFA_PBS_ASM%s_KEY_SCALE_LOG2 %d, %d\n" % ("" if WAVES == 8 else "4", *((-22, -12) if FP_DIGITS else (0, 0))))
     stats = {}
     for ln in lines:
