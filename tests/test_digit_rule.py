@@ -61,20 +61,20 @@ def asm_sequence(v, r, m, acc):
 
 def fp_sequence(x):
     """the hand-scheduled wide loop's digits ("fp_digits" in tools/pbs_asm/gen.py): the biased, masked difference becomes the
-    low mantissa word of 2^52 + x, V = that double - (2^52 + 2^31 - 2^21) is the rounded difference in the window
-    [-2^31 + 2^21, 2^31 + 2^21), t = V (1 - 2^-21) + 1.5 * 2^74 rounds V to the nearest multiple of 2^22 with ties toward
-    zero (one IEEE rounding), and the loop keeps -d1 2^22 = 1.5 * 2^74 - t and d2 2^12 = V + that; x = sign * v - acc"""
+    low mantissa word of the double 2^40 + w 2^-12, V = that double - (2^40 + 2^19 - 2^9) is the rounded difference in units
+    of 2^12 (an integer in [-2^19 + 512, 2^19 + 512)), t = V (1 - 2^-21) / 1024 + 1.5 * 2^52 rounds V / 1024 to the nearest
+    integer with ties toward zero (one IEEE rounding), and the loop keeps -d1 = 1.5 * 2^52 - t and d2 = V + 1024 (-d1);
+    x = sign * v - acc"""
     with np.errstate(over="ignore"):
         w = (x.astype(np.uint32) + np.uint32((0x800 + 0x80000000 - 0x200000) & 0xFFFFFFFF)) & np.uint32(0xFFFFF000)
-    d = (np.uint64(0x4330000000000000) | w.astype(np.uint64)).view(np.float64)
-    v = d - (2.0 ** 52 + 2.0 ** 31 - 2.0 ** 21)
-    m74 = 1.5 * 2.0 ** 74
-    t = v * (1.0 - 2.0 ** -21) + m74          # the product is exact (43 significant bits), so this is the fused result
-    neg_hi = m74 - t
-    lo = v + neg_hi
-    d1, d2 = -neg_hi / 2.0 ** 22, lo / 2.0 ** 12
-    assert (d1 == np.rint(d1)).all() and (d2 == np.rint(d2)).all()
-    return d1.astype(np.int64), d2.astype(np.int64)
+    d = (np.uint64(0x4270000000000000) | w.astype(np.uint64)).view(np.float64)
+    v = d - (2.0 ** 40 + 2.0 ** 19 - 2.0 ** 9)
+    magic = 1.5 * 2.0 ** 52
+    t = v * ((1.0 - 2.0 ** -21) / 1024.0) + magic     # the product is exact (42 significant bits), so this is the fused result
+    neg_d1 = magic - t
+    d2 = v + 1024.0 * neg_d1
+    assert (v == np.rint(v)).all() and (neg_d1 == np.rint(neg_d1)).all()
+    return (-neg_d1).astype(np.int64), d2.astype(np.int64)
 
 
 def test_fp_sequence_every_state():

@@ -307,8 +307,6 @@ def fourier_key_lanesum(bsk, n_steps):
                 for c in range(4):
                     p = b[i, lv, r, c]
                     F[r, c] = np.fft.ifft((p[:256] + 1j * p[256:]) * tw)
-            if G.FP_DIGITS:       # the loop's digits are scaled by 2^22 / 2^12 (exact, so the products are the same numbers)
-                F *= G.KEY_SCALE[lv]
             for k_lo in range(4):
                 for j in range(4):
                     for jp in range(4):

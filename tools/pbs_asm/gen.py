@@ -49,17 +49,16 @@ STEP_KEY_BYTES = 131072
 MAGIC = 6755399441055744.0  # 1.5 * 2^52
 # "fp_digits": both digits of a coefficient come out of four fp64 instructions instead of seven integer ones and two
 # conversions.  x = (sign * acc[src] - acc + 2^11 + 2^31 - 2^21) & ~0xfff is written into the low word of a register pair whose
-# high word holds 0x43300000, so the pair reads as the double 2^52 + x; V = pair - (2^52 + 2^31 - 2^21) is the rounded
-# difference as a signed multiple of 2^12 in [-2^31 + 2^21, 2^31 + 2^21), the window in which the top digit is the tfhe-rs
-# one, [-511, 512].  The low digit's rule (carry when the residue exceeds B/2, or equals B/2 and the state's top bit is set) is
-# "nearest multiple of 2^22, ties toward zero" on V: t = V (1 - 2^-21) + 1.5 * 2^74 (exact product, one rounding at a unit of
-# 2^22; the factor moves a tie by at least 1 and nothing by 2^12 or more), d1 2^22 = t - 1.5 * 2^74, d2 2^12 = V - d1 2^22, all
-# exact.  The key of the lane-local-sum layout carries the factors 2^-22 / 2^-12 (exact scalings: same rounded results).
+# high word holds 0x42700000, so the pair reads as the double 2^40 + x 2^-12; V = pair - (2^40 + 2^19 - 2^9) is the rounded
+# difference in units of 2^12, an integer in [-2^19 + 512, 2^19 + 512), the window in which the top digit is the tfhe-rs one,
+# [-511, 512].  The low digit's rule (carry when the residue exceeds B/2, or equals B/2 and the state's top bit is set) is
+# "V / 1024 to the nearest integer, ties toward zero": t = V (1 - 2^-21) / 1024 + 1.5 * 2^52 (exact product, one rounding at a
+# unit of 1; the factor moves a tie by at least 2^-22 and nothing by 2^-10 or more), -d1 = 1.5 * 2^52 - t, d2 = V + 1024 (-d1),
+# all exact.
 DIGIT_BIAS = (0x800 + 0x80000000 - 0x200000) & 0xFFFFFFFF
-DIGIT_K = 2.0 ** 52 + 2.0 ** 31 - 2.0 ** 21
-DIGIT_C = 1.0 - 2.0 ** -21
-MAGIC74 = 1.5 * 2.0 ** 74
-KEY_SCALE = (2.0 ** -22, 2.0 ** -12)      # per level, folded into the key by its layout kernel when FP_DIGITS
+DIGIT_HI = 0x42700000
+DIGIT_K = 2.0 ** 40 + 2.0 ** 19 - 2.0 ** 9
+DIGIT_C = (1.0 - 2.0 ** -21) / 1024.0
 
 
 def kperm(p):
@@ -75,7 +74,7 @@ S_M0ROW = 13    # LDS byte address of this wave's first DMA row in ring slot 0
 S_TMP = 14      # s[14:15] scratch pair (DMA row pointer)
 S_C2048 = 16
 S_C511 = 17
-S_ROTM0 = 96     # LDS byte address of this wave's rotation buffer (for the M0-relative stores)
+S_ROTM0 = 100    # LDS byte address of this wave's rotation buffer (for the M0-relative stores)
 S_CONST0 = 18   # fp64 constants from here, in pairs
 
 
@@ -95,7 +94,6 @@ V_TWF = 13                       # lanesum: twiddle row address with this lane's
 V_AREAD = 19                     # next step's rotation amount (u16 read from LDS)
 V_SCR = list(range(20, 30))      # scratch ints; also v[20:21], v[22:23] as fp64 scratch of the twiddle products
 V_MAGIC = 30                     # v[30:31] = 1.5 * 2^52
-V_MAGIC74 = 14                   # v[14:15] = 1.5 * 2^74 (fp_digits: rounds to multiples of 2^22)
 V_ACC = 32
 R_A, R_B, R_K, R_T = 64, 128, 192, 224
 
@@ -126,7 +124,7 @@ class Consts:
             self.idx[key] = len(self.vals)
             self.vals.append(key)
         r = const_reg(self.idx[key])
-        assert r + 1 <= 101, "out of scalar registers for constants"
+        assert r + 1 < S_ROTM0, "out of scalar registers for constants"
         return "s[%d:%d]" % (r, r + 1)
 
 
@@ -402,7 +400,6 @@ class Loop:
                 e("v_lshl_add_u32 v%d, v%d, 13, v%d" % (tmp, tmp, a0))      # a0 - 8192 once wrapped
             e("ds_read_b32 v%d, v%d offset:%d" % (R_K + m, tmp, 256 * m))
         if FP_DIGITS:
-            assert LANESUM, "the key scaling of fp_digits lives in the lane-local-sum layout"
             self.digits_fp(fs)
             return
         # the m-th read has returned when at most 31 - m younger ones are in flight (the counter saturates at 15)
@@ -439,15 +436,15 @@ class Loop:
 
     def digits_fp(self, fs):
         """digits of the 32 rotated coefficients in R_K (see FP_DIGITS above), four coefficients at a time so that no
-        instruction follows the one it depends on; array A <- -d1 2^22, array B <- d2 2^12"""
+        instruction follows the one it depends on; array A <- -d1, array B <- d2"""
         e = self.e
         G_ = int(os.environ.get("PBS_ASM_FPG", "0"))
         if G_:
-            # measurement variant: groups of G_ coefficients, no temporaries for the doubles: the pair (x, 0x43300000) is array B's
+            # measurement variant: groups of G_ coefficients, no temporaries for the doubles: the pair (x, DIGIT_HI) is array B's
             # slot itself (its high word written per coefficient), V replaces it in place, t sits in array A's slot
             sg = [R_T + j for j in range(G_)]
             cy = [R_T + 16 + j for j in range(G_)]
-            kreg, creg = self.consts.get(DIGIT_K), self.consts.get(DIGIT_C)
+            kreg, creg, c1024 = self.consts.get(DIGIT_K), self.consts.get(DIGIT_C), self.consts.get(1024.0)
             for m0 in range(0, 32, G_):
                 ms = range(m0, m0 + G_)
                 for j, m in enumerate(ms):
@@ -460,24 +457,24 @@ class Loop:
                     e("v_xad_u32 v%d, v%d, v%d, v%d" % (cy[j], R_K + m, sg[j], cy[j]))
                 for j, m in enumerate(ms):
                     e("v_and_b32 v%d, s%d, v%d" % (R_B + 2 * m, S_C511, cy[j]))
-                    e("v_mov_b32 v%d, 0x43300000" % (R_B + 2 * m + 1))
+                    e("v_mov_b32 v%d, 0x%x" % (R_B + 2 * m + 1, DIGIT_HI))
                 for m in ms:
                     e("v_add_f64 %s, %s, -%s" % (dreg(R_B + 2 * m), dreg(R_B + 2 * m), kreg))
                 for m in ms:
-                    e("v_fma_f64 %s, %s, %s, %s" % (dreg(R_A + 2 * m), dreg(R_B + 2 * m), creg, dreg(V_MAGIC74)))
+                    e("v_fma_f64 %s, %s, %s, %s" % (dreg(R_A + 2 * m), dreg(R_B + 2 * m), creg, dreg(V_MAGIC)))
                 for m in ms:
-                    e("v_add_f64 %s, %s, -%s" % (dreg(R_A + 2 * m), dreg(V_MAGIC74), dreg(R_A + 2 * m)))
+                    e("v_add_f64 %s, %s, -%s" % (dreg(R_A + 2 * m), dreg(V_MAGIC), dreg(R_A + 2 * m)))
                 for m in ms:
-                    e("v_add_f64 %s, %s, %s" % (dreg(R_B + 2 * m), dreg(R_B + 2 * m), dreg(R_A + 2 * m)))
+                    e("v_fma_f64 %s, %s, %s, %s" % (dreg(R_B + 2 * m), dreg(R_A + 2 * m), c1024, dreg(R_B + 2 * m)))
             return
-        D = [R_T + 2 * j for j in range(4)]              # (x, 0x43300000) pairs
+        D = [R_T + 2 * j for j in range(4)]              # (x, DIGIT_HI) pairs
         Vv = [R_T + 8 + 2 * j for j in range(4)]
         Tt = [R_T + 16 + 2 * j for j in range(4)]
         sg = [R_T + 24 + j for j in range(4)]
         cy = [R_T + 28 + j for j in range(4)]
         for j in range(4):
-            e("v_mov_b32 v%d, 0x43300000" % (D[j] + 1))
-        kreg, creg = self.consts.get(DIGIT_K), self.consts.get(DIGIT_C)
+            e("v_mov_b32 v%d, 0x%x" % (D[j] + 1, DIGIT_HI))
+        kreg, creg, c1024 = self.consts.get(DIGIT_K), self.consts.get(DIGIT_C), self.consts.get(1024.0)
         for m0 in range(0, 32, 4):
             for j in range(4):
                 self.lds_wait(min(15, 31 - (m0 + j)))
@@ -492,11 +489,11 @@ class Loop:
             for j in range(4):
                 e("v_add_f64 %s, %s, -%s" % (dreg(Vv[j]), dreg(D[j]), kreg))
             for j in range(4):
-                e("v_fma_f64 %s, %s, %s, %s" % (dreg(Tt[j]), dreg(Vv[j]), creg, dreg(V_MAGIC74)))
+                e("v_fma_f64 %s, %s, %s, %s" % (dreg(Tt[j]), dreg(Vv[j]), creg, dreg(V_MAGIC)))
             for j in range(4):
-                e("v_add_f64 %s, %s, -%s" % (dreg(R_A + 2 * (m0 + j)), dreg(V_MAGIC74), dreg(Tt[j])))
+                e("v_add_f64 %s, %s, -%s" % (dreg(R_A + 2 * (m0 + j)), dreg(V_MAGIC), dreg(Tt[j])))
             for j in range(4):
-                e("v_add_f64 %s, %s, %s" % (dreg(R_B + 2 * (m0 + j)), dreg(Vv[j]), dreg(R_A + 2 * (m0 + j))))
+                e("v_fma_f64 %s, %s, %s, %s" % (dreg(R_B + 2 * (m0 + j)), dreg(R_A + 2 * (m0 + j)), c1024, dreg(Vv[j])))
 
     # ---- twiddles -------------------------------------------------------------------------------------------------------
     def tw_issue(self, k0, count, region):
@@ -923,10 +920,6 @@ class Loop:
         mbits = struct.unpack("<Q", struct.pack("<d", MAGIC))[0]
         e("v_mov_b32 v%d, 0x%x" % (V_MAGIC, mbits & 0xFFFFFFFF))
         e("v_mov_b32 v%d, 0x%x" % (V_MAGIC + 1, mbits >> 32))
-        if FP_DIGITS:
-            mbits = struct.unpack("<Q", struct.pack("<d", MAGIC74))[0]
-            e("v_mov_b32 v%d, 0x%x" % (V_MAGIC74, mbits & 0xFFFFFFFF))
-            e("v_mov_b32 v%d, 0x%x" % (V_MAGIC74 + 1, mbits >> 32))
         if "dma_off" in OPT:
             e("v_add_u32 v%d, 0x%x, v%d" % (V_KADDR, K_RING_OFFSET, V_KBASE))
         if "shift4" in OPT:      # measurement: the loop's instruction stream moved by four bytes (placement sensitivity)
@@ -1100,9 +1093,7 @@ def main():
             f.write('    "%s\\n\\t" \\\n' % ln)
         f.write('    ""\n')
         f.write("#define TFA_PBS_ASM%s_CLOBBERS %s\n" % ("" if WAVES == 8 else "4", ", ".join(cl + ['"memory"', '"scc"', '"vcc"'])))
-        # what the loop expects of the key: the per-level power-of-two factors its digits carry (1, 1 without fp_digits)
         f.write("#define TFA_PBS_ASM%s_RING_AHEAD %d\n" % ("" if WAVES == 8 else "4", RING_AHEAD))      # chunks in flight when the loop starts
-        f.write("#define TFA_PBS_ASM%s_KEY_SCALE_LOG2 %d, %d\n" % ("" if WAVES == 8 else "4", *((-22, -12) if FP_DIGITS else (0, 0))))
     stats = {}
     for ln in lines:
         op = ln.split()[0]

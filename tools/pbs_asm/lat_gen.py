@@ -54,6 +54,13 @@ MAGIC = 6755399441055744.0
 S_STEPS, S_ACUR, S_A, S_PAR, S_TMP = 10, 11, 12, 13, 14
 S_C2048 = 16
 S_C511 = 17
+S_DK, S_DC, S_D1024 = 40, 42, 44           # fp64 constants of digits_fp: 2^40 + 2^19 - 2^9, (1 - 2^-21) / 1024, 1024
+# Digits of the decomposition: 0 (shipped) the integer sequence; 1 / 2 the wide loop's floating-point digits (digits_fp), two /
+# eight coefficients at a time.  Measured in one GPU call (ms per stage of 128 / 256 / 512 bootstraps): integer 2.29 / 2.38 /
+# 3.95, two at a time 2.36 / 2.45 / 3.91, eight at a time 2.32 / 2.42 / 3.95: with one wave per SIMD the longer dependent
+# chain of the fp64 form costs more than its 30 fewer instructions save, with two it is even.
+FPD_MODE = int(os.environ.get("PBS_LAT_FPD", "0"))
+FP_DIGITS = FPD_MODE != 0
 S_TW = 38                                 # s[38:39] twiddle table in global memory (prologue only)
 
 
@@ -180,6 +187,9 @@ class Lat:
             e("v_bfe_i32 v%d, v%d, %d, 1" % (tmp, fw, m))
             e("v_lshl_add_u32 v%d, v%d, 11, v%d" % (tmp, tmp, a0))
             e("ds_read_b32 v%d, v%d offset:%d" % (rk[m], tmp, 256 * m))
+        if FP_DIGITS:
+            self.digits_fp(fs, rk)
+            return
         sg, c, y, s_, u, w = V_SCR[3], V_SCR[4], V_SCR[5], V_SCR[6], V_SCR[7], V_SCR[8]
         for m in range(8):
             v = rk[m]
@@ -197,6 +207,64 @@ class Lat:
             e("v_and_b32 v%d, 0xfffffc00, v%d" % (u, u))
             e("v_sub_u32 v%d, v%d, v%d" % (u, s_, u))                    # d2
             e("v_cvt_f64_i32 %s, v%d" % (dreg(R_Z[1] + 4 * q + part), u))
+
+    def digits_fp(self, fs, rk):
+        """Both digits of a coefficient from four fp64 instructions.  x = (sign * acc[src] - acc + 2^11 + 2^31 - 2^21) & ~0xfff is
+        written into the low word of a register pair whose high word holds 0x42700000, so the pair reads as the double
+        2^40 + x 2^-12; V = pair - (2^40 + 2^19 - 2^9) is the rounded difference in units of 2^12, an integer in
+        [-2^19 + 512, 2^19 + 512), the window in which the top digit is the tfhe-rs one, [-511, 512].  The low digit's rule
+        (carry when the residue exceeds B/2, or equals B/2 and the state's top bit is set) is "V / 1024 to the nearest integer,
+        ties toward zero": t = V (1 - 2^-21) / 1024 + 1.5 * 2^52 (the product is exact, one rounding at a unit of 1; the factor
+        moves a tie by at least 2^-22 and nothing by 2^-10 or more), -d1 = 1.5 * 2^52 - t, d2 = V + 1024 (-d1), all exact.
+        Two coefficients at a time, so that no instruction follows the one it depends on."""
+        e = self.e
+        if FPD_MODE == 2:
+            # all eight coefficients side by side, stage by stage, with no scratch register: the sign mask sits in the low word
+            # of the coefficient's level-1 slot until t takes the slot, the biased difference and then the pair
+            # (x, 0x42700000) in its level-2 slot, whose high word is written per coefficient
+            z = [(R_Z[0] + 4 * (m & 3) + (0 if m < 4 else 2), R_Z[1] + 4 * (m & 3) + (0 if m < 4 else 2)) for m in range(8)]
+            for m in range(8):
+                e("v_bfe_i32 v%d, v%d, %d, 1" % (z[m][0], fs, m))
+            for m in range(8):
+                e("v_bfe_u32 v%d, v%d, %d, 1" % (z[m][1], fs, m))
+            for m in range(8):
+                e("v_add3_u32 v%d, v%d, v%d, s%d" % (z[m][1], z[m][1], V_ACC + m, S_C2048))
+            for m in range(8):
+                e("v_xad_u32 v%d, v%d, v%d, v%d" % (z[m][1], rk[m], z[m][0], z[m][1]))
+            for m in range(8):
+                e("v_and_b32 v%d, 0xfffff000, v%d" % (z[m][1], z[m][1]))
+                e("v_mov_b32 v%d, 0x42700000" % (z[m][1] + 1))
+            for m in range(8):
+                e("v_add_f64 %s, %s, -s[%d:%d]" % (dreg(z[m][1]), dreg(z[m][1]), S_DK, S_DK + 1))
+            for m in range(8):
+                e("v_fma_f64 %s, %s, s[%d:%d], %s" % (dreg(z[m][0]), dreg(z[m][1]), S_DC, S_DC + 1, dreg(V_MAGIC)))
+            for m in range(8):
+                e("v_add_f64 %s, %s, -%s" % (dreg(z[m][0]), dreg(V_MAGIC), dreg(z[m][0])))                     # -d1
+            for m in range(8):
+                e("v_fma_f64 %s, %s, s[%d:%d], %s" % (dreg(z[m][1]), dreg(z[m][0]), S_D1024, S_D1024 + 1, dreg(z[m][1])))   # d2
+            return
+        D = [V_SCR[5], V_SCR[7]]                   # v[24:25], v[26:27]; the high words are set once, in front of the loop
+        sg, cy = [V_SCR[3], R_T + 8], [V_SCR[4], R_T + 9]
+        for m0 in range(0, 8, 2):
+            ms = (m0, m0 + 1)
+            for j, m in enumerate(ms):
+                e("v_bfe_i32 v%d, v%d, %d, 1" % (sg[j], fs, m))
+                e("v_bfe_u32 v%d, v%d, %d, 1" % (cy[j], fs, m))
+            for j, m in enumerate(ms):
+                e("v_add3_u32 v%d, v%d, v%d, s%d" % (cy[j], cy[j], V_ACC + m, S_C2048))
+            for j, m in enumerate(ms):
+                e("v_xad_u32 v%d, v%d, v%d, v%d" % (cy[j], rk[m], sg[j], cy[j]))
+            for j, m in enumerate(ms):
+                e("v_and_b32 v%d, 0xfffff000, v%d" % (D[j], cy[j]))
+            z = [(dreg(R_Z[0] + 4 * (m & 3) + (0 if m < 4 else 2)), dreg(R_Z[1] + 4 * (m & 3) + (0 if m < 4 else 2))) for m in ms]
+            for j in range(2):
+                e("v_add_f64 %s, %s, -s[%d:%d]" % (z[j][1], dreg(D[j]), S_DK, S_DK + 1))
+            for j in range(2):
+                e("v_fma_f64 %s, %s, s[%d:%d], %s" % (z[j][0], z[j][1], S_DC, S_DC + 1, dreg(V_MAGIC)))
+            for j in range(2):
+                e("v_add_f64 %s, %s, -%s" % (z[j][0], dreg(V_MAGIC), z[j][0]))                     # -d1
+            for j in range(2):
+                e("v_fma_f64 %s, %s, s[%d:%d], %s" % (z[j][1], z[j][0], S_D1024, S_D1024 + 1, z[j][1]))   # d2
 
     def forward(self):
         """both levels, interleaved stage by stage: one level's hand-over travels under the other's butterfly.
@@ -343,8 +411,17 @@ class Lat:
         body.consts, body.out = self.consts, []
         body.step()
         mbits = struct.unpack("<Q", struct.pack("<d", MAGIC))[0]
-        e("s_mov_b32 s%d, 0x800" % S_C2048)
-        e("s_mov_b32 s%d, 0x1ff" % S_C511)
+        if FP_DIGITS:
+            e("s_mov_b32 s%d, 0x%x" % (S_C2048, (0x800 + 0x80000000 - 0x200000) & 0xFFFFFFFF))
+            for reg, val in ((S_DK, 2.0 ** 40 + 2.0 ** 19 - 2.0 ** 9), (S_DC, (1.0 - 2.0 ** -21) / 1024.0), (S_D1024, 1024.0)):
+                bits = struct.unpack("<Q", struct.pack("<d", val))[0]
+                e("s_mov_b32 s%d, 0x%x" % (reg, bits & 0xFFFFFFFF))
+                e("s_mov_b32 s%d, 0x%x" % (reg + 1, bits >> 32))
+            e("v_mov_b32 v%d, 0x42700000" % (V_SCR[5] + 1))
+            e("v_mov_b32 v%d, 0x42700000" % (V_SCR[7] + 1))
+        else:
+            e("s_mov_b32 s%d, 0x800" % S_C2048)
+            e("s_mov_b32 s%d, 0x1ff" % S_C511)
         e("v_readfirstlane_b32 s%d, v%d" % (S_TMP, V_ROTBASE))         # nothing else in this loop uses M0
         e("s_mov_b32 m0, s%d" % S_TMP)
         e("v_mov_b32 v%d, 0x%x" % (V_MAGIC, mbits & 0xFFFFFFFF))
