@@ -903,6 +903,8 @@ class Loop:
                      "short": ["v_add_u32 v%d, v3, v3" % r for r in (24, 25, 26)],
                      "dpp": ["v_mov_b32_dpp v%d, v3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" % r for r in (24, 25, 26)],
                      "lds": ["ds_read_b32 v%d, v17" % r for r in (24, 25, 26)],
+                     "lds128": ["ds_read_b128 v[24:27], v%d offset:%d" % (V_KBASE, 1024 * k) for k in range(3)],     # conflict-free 16-byte reads
+                     "vmem128": ["global_load_dwordx4 v[24:27], v%d, s[%d:%d]" % (V_LANE16, S_KP, S_KP + 1)] * 3,     # the same bytes from L1 / L2
                      "salu": ["s_add_u32 s97, s97, 1"] * 3}[kind]
             valu_at = [i for i, ln in enumerate(body.out) if ln.startswith("v_")]
             picks = [valu_at[(2 * k + 1) * len(valu_at) // (2 * count)] for k in range(count)]
