@@ -894,7 +894,16 @@ class Loop:
         # step (they write registers nothing reads, so the results stay bit-exact): what one more instruction of that class
         # costs inside this loop
         pad = os.environ.get("PBS_ASM_PAD", "")
-        if pad:
+        if pad.startswith("dup:"):
+            # every LDS instruction of one opcode issued twice in a row (same addresses, same data: harmless): its cost in situ
+            opc = pad.split(":")[1]
+            dup = []
+            for ln in body.out:
+                dup.append(ln)
+                if ln.split()[0] == opc and ("exch" not in pad or any(", v%d " % r in ln + " " or ln.startswith(opc + " v%d," % r) for r in V_TRWR + V_TRRD)):
+                    dup.append(ln)
+            body.out = dup
+        elif pad:
             kind, count = pad.split(":")
             count = int(count)
             forms = {"f64": ["v_add_f64 v[%d:%d], v[30:31], v[30:31]" % (r, r + 1) for r in (24, 26, 28)],
